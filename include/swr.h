@@ -1,0 +1,162 @@
+/*
+ * swr.h — C-ABI of the MI355X-native triangle rasterizer (drop-in boundary).
+ *
+ * This header is the whole boundary: plain pointers and sizes, no C++ / torch / HIP
+ * types.  Every entry point names the reference interface (file:line relative to
+ * zhvrnkov/software-renderer) that it stands in for.  The shared library that exports
+ * these symbols is `software-renderer_amd/lib/libswr_hip.so` (built from
+ * `software-renderer_amd/csrc/` with hipcc for gfx950).  There is no CPU fallback inside
+ * the library: every entry point that computes needs a HIP device and returns
+ * SWR_ERR_HIP (with a message in swr_last_error) when there is none.
+ *
+ * Semantics are those of the reference's CPU renderer (renderer/Renderer.swift:204-287,
+ * 467-494, 88-100, 116-129, 159-171) — see DESIGN.md §2 for the normative restatement.
+ */
+#ifndef SWR_H_
+#define SWR_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWR_ABI_VERSION 1
+
+/* ---- status codes (the reference has no error channel: it fatalError()s / try!s,
+ *      Renderer.swift:26,209,239,497; GpuRenderer.swift:20-31,37-38) ------------------ */
+enum {
+    SWR_OK = 0,
+    SWR_ERR_BAD_ARG = -1,       /* null pointer, non-positive size, bad band */
+    SWR_ERR_INDEX_COUNT = -2,   /* index_count % 3 != 0   (assert, Renderer.swift:209) */
+    SWR_ERR_INDEX_RANGE = -3,   /* an index outside [0, vertex_count)  (Swift array trap, Renderer.swift:226) */
+    SWR_ERR_HIP = -4,           /* HIP runtime error / no device */
+    SWR_ERR_UNSUPPORTED = -5,   /* primitive type not on the hot path (.line / .vertices), too many primitives */
+    SWR_ERR_NO_SCENE = -6,      /* swr_draw before swr_scene_upload / swr_target_set */
+    SWR_ERR_NOMEM = -7
+};
+
+/* ---- PrimitiveType (Renderer.swift:174-189).  Only .triangle is on the hot path. ---- */
+enum {
+    SWR_PRIMITIVE_TRIANGLE = 0,
+    SWR_PRIMITIVE_LINE = 1,      /* reference draw(line:) is an empty stub, Renderer.swift:289-293 */
+    SWR_PRIMITIVE_VERTICES = 2   /* Renderer.swift:295-302 — out of scope this round */
+};
+
+/* ---- draw flags --------------------------------------------------------------------- */
+enum {
+    /* 0 = the CPU renderer exactly as written: painter's order (highest primitive index
+     * covering a pixel wins), depth image stays +inf (z-test commented out,
+     * Renderer.swift:257-261). */
+    SWR_FLAG_DEPTH_TEST = 1u << 0, /* restore Renderer.swift:257-261: depth = za*w0+zb*w1+zc*w2,
+                                      strict '<', first-drawn wins ties (also :344-348,
+                                      Shaders.metal:158-165) */
+    SWR_FLAG_NO_COLOR   = 1u << 1  /* depth-only pass: the colour image is neither cleared nor
+                                      written (BASELINE config 4) */
+};
+
+/* ---- Vertex (Renderer.swift:154-157): two SIMD3<Float>, each padded to 16 B --------- */
+typedef struct swr_vertex {
+    float xyz[4];    /* x,y,z, lane 3 = padding (ignored) */
+    float color[4];  /* r,g,b, lane 3 = padding (ignored) */
+} swr_vertex;        /* 32 bytes */
+
+/* ---- RenderPass (Renderer.swift:191-200) + Image<T> (Renderer.swift:8-21) ------------
+ * color: Pixel = {b,g,r,a} u8 (Renderer.swift:44-49); element (x,y) at color[y*width+x]
+ * (App.swift:351-360: addressing uses width; bytesPerRow is stored but never read, so
+ * the two *_bytes_per_row fields are carried for layout parity and ignored). */
+typedef struct swr_render_pass {
+    void*    color;                 /* width*height*4 bytes, BGRA8; may be NULL iff SWR_FLAG_NO_COLOR */
+    float*   depth;                 /* width*height floats */
+    int64_t  width;
+    int64_t  height;
+    int64_t  color_bytes_per_row;   /* ignored, see above */
+    int64_t  depth_bytes_per_row;   /* ignored */
+    const swr_vertex* vertices;
+    int64_t  vertex_count;
+    const int64_t* indices;         /* Swift Int (Renderer.swift:196) */
+    int64_t  index_count;
+    int32_t  primitive_type;        /* SWR_PRIMITIVE_* ; default .triangle (Renderer.swift:197) */
+    uint32_t flags;                 /* SWR_FLAG_* */
+    float    transform[16];         /* matrix_float4x4, column-major: column c = transform[4c..4c+3]
+                                       (Renderer.swift:199) */
+} swr_render_pass;
+
+typedef struct swr_config {
+    int32_t  device;     /* HIP device ordinal; -1 = current device */
+    uint32_t reserved;
+} swr_config;
+
+/* Per-kernel device times of the last swr_draw / swr_render on this context, measured with
+ * hipEvents recorded on the context's own stream (only filled when timing is enabled). */
+typedef struct swr_timings {
+    float setup_bin_ms;   /* vertex transform + triangle setup + tile binning (count/emit) */
+    float scan_ms;        /* per-tile offsets */
+    float scatter_ms;     /* bin fill */
+    float raster_ms;      /* tile raster + resolve + framebuffer write (the dominant kernel) */
+    float total_ms;       /* first kernel start -> last kernel end */
+    int64_t tile_pairs;   /* (triangle,tile) pairs binned in the frame */
+    int64_t tiles;        /* tiles in the band */
+    int64_t triangles;    /* primitives submitted */
+} swr_timings;
+
+typedef struct swr_context swr_context;
+
+/* Library / ABI identification. */
+int         swr_abi_version(void);
+const char* swr_version(void);
+
+/* GpuRenderer() / Renderer() default initialisers (App.swift:148-149) + MTLContext.shared
+ * (Metal+Extensions.swift:5-45): device, stream, cached scratch buffers. */
+int  swr_context_create(const swr_config* cfg, swr_context** out);
+void swr_context_destroy(swr_context* ctx);
+
+/* Last error text for this context (NULL ctx: last error of a failed swr_context_create). */
+const char* swr_last_error(const swr_context* ctx);
+
+/* Renderer.render(renderPass:) (Renderer.swift:204-230) and GpuRenderer.render(renderPass:)
+ * (GpuRenderer.swift:35-90): caller-owned host memory in, colour + depth images filled on
+ * return (synchronous, like scheduleAndWait, Metal+Extensions.swift:57-67). */
+int swr_render(swr_context* ctx, const swr_render_pass* pass);
+
+/* ---- resident path: what the app's frame loop does (App.swift:153-185) — same mesh every
+ * frame, new transform — without re-uploading; inputs and outputs stay in HBM. ----------- */
+
+/* RenderPass.vertices / .indices (Renderer.swift:195-196); replaces the per-frame
+ * makeBuffer / setBytes uploads of GpuRenderer.swift:68-71,93-103.  Validates indices. */
+int swr_scene_upload(swr_context* ctx, const swr_vertex* vertices, int64_t vertex_count,
+                     const int64_t* indices, int64_t index_count);
+
+/* colorBuffer / depthBuffer size (Renderer.swift:192-193).  row_begin/row_end select the
+ * tile-row band [row_begin,row_end) of the framebuffer this context (GPU) owns; pass
+ * 0,height for the whole image.  row_begin must be a multiple of swr_tile_rows(). */
+int swr_target_set(swr_context* ctx, int64_t width, int64_t height,
+                   int64_t row_begin, int64_t row_end);
+
+/* One frame: clear + all triangles (Renderer.swift:204-230) into the device-resident band.
+ * Asynchronous on the context stream; swr_sync() or a swr_read_* completes it. */
+int swr_draw(swr_context* ctx, const float transform[16], uint32_t flags);
+int swr_sync(swr_context* ctx);
+
+/* Copy the band's rows into the caller's FULL-size host images (rows [row_begin,row_end) of
+ * dst are written, others untouched) — the pinned-memory gather of a multi-GPU frame. */
+int swr_read_color(swr_context* ctx, void* dst_full_image);
+int swr_read_depth(swr_context* ctx, float* dst_full_image);
+
+/* Timing instrumentation (hipEvents on the context stream around each kernel). */
+int swr_timing_enable(swr_context* ctx, int enable);
+int swr_get_timings(swr_context* ctx, swr_timings* out);
+
+/* Tile geometry the band boundaries must respect. */
+int swr_tile_rows(void);
+int swr_tile_cols(void);
+
+/* Helper: split `height` rows into `parts` contiguous bands aligned to swr_tile_rows();
+ * writes row_begin/row_end of band `part`.  Pure host arithmetic (no device needed). */
+int swr_band_rows(int64_t height, int32_t parts, int32_t part,
+                  int64_t* row_begin, int64_t* row_end);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWR_H_ */

@@ -1,0 +1,106 @@
+"""ctypes wrapper of oracle/libswr_oracle.so — TEST INFRASTRUCTURE (parity unpinned, see
+swr_oracle.h).  Importable only from tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; the product package never imports this module."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, "libswr_oracle.so")
+
+DEPTH_TEST = 1 << 0
+NO_COLOR = 1 << 1
+INV_RCP = 1 << 8
+UNCLAMPED = 1 << 9
+TINV_PER_TRIANGLE = 1 << 10
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("fragments", ctypes.c_int64), ("fragments_written", ctypes.c_int64),
+                ("triangles_drawn", ctypes.c_int64), ("triangles_skipped", ctypes.c_int64)]
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "swr_oracle.c")
+    if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-s", "libswr_oracle.so"])
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_LIB_PATH)
+        L.swro_render.restype = ctypes.c_int
+        L.swro_render.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                  ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                  ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int64, ctypes.c_int64,
+                                  ctypes.POINTER(Stats)]
+        L.swro_interpolate.restype = ctypes.c_int64
+        L.swro_interpolate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]
+        L.swro_quantise.restype = ctypes.c_uint8
+        L.swro_quantise.argtypes = [ctypes.c_float]
+        _lib = L
+    return _lib
+
+
+def render(vertices: np.ndarray, indices: np.ndarray, transform: np.ndarray, width: int, height: int,
+           flags: int = 0, row_begin: int = 0, row_end: int | None = None,
+           color: np.ndarray | None = None, depth: np.ndarray | None = None):
+    """Returns (color uint8[H,W,4] BGRA or None, depth float32[H,W], Stats, rc)."""
+    L = lib()
+    v = np.ascontiguousarray(vertices, dtype=np.float32)
+    i = np.ascontiguousarray(indices, dtype=np.int64)
+    m = np.ascontiguousarray(transform, dtype=np.float32)
+    if row_end is None:
+        row_end = height
+    if color is None and not (flags & NO_COLOR):
+        color = np.full((height, width, 4), 0xCD, dtype=np.uint8)
+    if depth is None:
+        depth = np.full((height, width), -123.0, dtype=np.float32)
+    st = Stats()
+    rc = L.swro_render(color.ctypes.data if color is not None else None, depth.ctypes.data,
+                       width, height, v.ctypes.data, v.shape[0] if v.ndim == 2 else v.size // 8,
+                       i.ctypes.data, i.size, m.ctypes.data, flags, row_begin, row_end,
+                       ctypes.byref(st))
+    return color, depth, st, rc
+
+
+def render_scene(scene, extra_flags: int = 0, **kw):
+    return render(scene.vertices, scene.indices, scene.transform, scene.width, scene.height,
+                  scene.flags | extra_flags, **kw)
+
+
+def render_threads(scene, threads: int, extra_flags: int = 0):
+    """Row-band N-thread run of the same oracle; ctypes drops the GIL."""
+    H, W = scene.height, scene.width
+    flags = scene.flags | extra_flags
+    color = None if (flags & NO_COLOR) else np.zeros((H, W, 4), dtype=np.uint8)
+    depth = np.zeros((H, W), dtype=np.float32)
+    edges = [H * k // threads for k in range(threads + 1)]
+
+    def job(k):
+        return render(scene.vertices, scene.indices, scene.transform, W, H, flags,
+                      edges[k], edges[k + 1], color, depth)[3]
+
+    with ThreadPoolExecutor(max_workers=threads) as ex:
+        rcs = list(ex.map(job, range(threads)))
+    return color, depth, rcs
+
+
+def interpolate(points, t: int) -> int:
+    p = np.ascontiguousarray(np.asarray(points, dtype=np.int64).reshape(-1))
+    return int(lib().swro_interpolate(p.ctypes.data, p.size // 2, t))
+
+
+def quantise(v: float) -> int:
+    return int(lib().swro_quantise(ctypes.c_float(v)))

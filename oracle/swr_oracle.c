@@ -1,0 +1,228 @@
+/*
+ * swr_oracle.c — CPU restatement of renderer/Renderer.swift's triangle path.
+ * TEST INFRASTRUCTURE (checker + reported CPU baseline).  PARITY UNPINNED — see swr_oracle.h.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fno-fast-math (no FMA contraction, IEEE binary32 ops,
+ * every intermediate rounded to float).  All "file:line" notes refer to
+ * /root/reference/renderer/Renderer.swift unless another file is named.
+ *
+ * Deviation (documented in DESIGN.md §2.4): a triangle with a non-finite screen coordinate,
+ * a screen coordinate whose magnitude is >= 2^30, or det == 0 is skipped.  The reference
+ * would trap (Int(NaN), UInt8(NaN)) or divide by zero there.
+ */
+#include "swr_oracle.h"
+
+#include <math.h>
+#include <stddef.h>
+#include <string.h>
+
+#define COORD_LIMIT 1073741824.0f /* 2^30 */
+
+typedef struct {
+    /* Vertex after apply(transform:) and convertedToScreen (floats), in index order a,b,c */
+    float sx[3], sy[3], sz[3];
+    float col[3][3];
+    /* simd_long2(a.xyz.xy) etc. (:251): truncated integer vertices in index order */
+    int64_t ix[3], iy[3];
+    /* sorted-by-float-y list, truncated (:271) */
+    int64_t sxs[3], sys_[3];
+} tri_t;
+
+typedef struct {
+    uint8_t* color;
+    float* depth;
+    int64_t W, H;
+    int64_t row_begin, row_end;
+    uint32_t flags;
+    swro_stats st;
+} frame_t;
+
+/* Pixel.floats (:117-124): UInt8(simd_clamp(v, 0, 1) * 255), truncation toward zero.
+ * simd_clamp = min(max(v,lo),hi) with fmax/fmin NaN handling (NaN -> lo). */
+uint8_t swro_quantise(float v) {
+    float c = fminf(fmaxf(v, 0.0f), 1.0f);
+    float s = c * 255.0f;
+    return (uint8_t)s;
+}
+
+/* Renderer.interpolate(values:t:) (:467-494). */
+int64_t swro_interpolate(const int64_t* p, int n, int64_t t) {
+    int base = 0;
+    if (n == 3) {                       /* :469-475 */
+        if (t >= p[2 * 2 + 1]) base = 2;
+        else if (t >= p[1 * 2 + 1]) base = 1;
+    }
+    int next = base + 1;                /* :476 */
+    int64_t sx = p[base * 2], sy = p[base * 2 + 1];
+    if (next >= n) return sx;           /* :478-480 */
+    int64_t ex = p[next * 2], ey = p[next * 2 + 1];
+    int64_t diff = ex - sx;             /* :484 */
+    int64_t dy = ey - sy;               /* :485 */
+    if (dy == 0) return sx;             /* :486-488 */
+    int64_t nt = t - sy;                /* :490 */
+    return sx + diff * nt / dy;         /* :492  (C '/' truncates toward zero like Swift Int '/') */
+}
+
+/* setPixel (:245-269).  noinline + per-call T() keeps the reference's per-pixel cost
+ * (the 2x2 inverse is recomputed for every pixel, :251-252 -> :88-100). */
+__attribute__((noinline))
+static void set_pixel(frame_t* f, const tri_t* t, int64_t x, int64_t y,
+                      const float* tinv_hoisted) {
+    /* :246-250 bounds check of both images (same size); band restriction for sharding */
+    if (x < 0 || x >= f->W || y < 0 || y >= f->H) return;
+    if (y < f->row_begin || y >= f->row_end) return;
+    f->st.fragments++;
+
+    float t00, t01, t10, t11;
+    /* Triangle.ws(xy:) (:88-93) with T() (:95-100) */
+    float cfx = (float)t->ix[2] + 0.5f, cfy = (float)t->iy[2] + 0.5f;   /* :89 */
+    if (tinv_hoisted) {
+        t00 = tinv_hoisted[0]; t01 = tinv_hoisted[1]; t10 = tinv_hoisted[2]; t11 = tinv_hoisted[3];
+    } else {
+        float afx = (float)t->ix[0] + 0.5f, afy = (float)t->iy[0] + 0.5f; /* :96 */
+        float bfx = (float)t->ix[1] + 0.5f, bfy = (float)t->iy[1] + 0.5f; /* :97 */
+        float m00 = afx - cfx, m10 = afy - cfy;   /* column 0 = af - cf (:99) */
+        float m01 = bfx - cfx, m11 = bfy - cfy;   /* column 1 = bf - cf */
+        float det = m00 * m11 - m01 * m10;
+        if (f->flags & SWRO_INV_RCP) {
+            float r = 1.0f / det;
+            t00 = m11 * r; t01 = -m01 * r; t10 = -m10 * r; t11 = m00 * r;
+        } else {                                  /* adjugate / determinant (Shaders.metal:15-31) */
+            t00 = m11 / det; t01 = -m01 / det; t10 = -m10 / det; t11 = m00 / det;
+        }
+    }
+    float px = (float)x + 0.5f, py = (float)y + 0.5f;   /* :252 */
+    float dx = px - cfx, dy = py - cfy;                 /* :91 (xy - cf) */
+    float w0 = t00 * dx + t01 * dy;                     /* :91 matrix*vector: col0*v.x + col1*v.y */
+    float w1 = t10 * dx + t11 * dy;
+    float w2 = 1.0f - w0 - w1;                          /* :92 */
+
+    size_t at = (size_t)(y * f->W + x);                 /* App.swift:351-360 */
+    if (f->flags & SWRO_DEPTH_TEST) {
+        float d = t->sz[0] * w0 + t->sz[1] * w1 + t->sz[2] * w2;  /* :257 */
+        if (!(d < f->depth[at])) return;                          /* :258-260 strict, NaN fails */
+        f->depth[at] = d;                                         /* :261 */
+    }
+    f->st.fragments_written++;
+    if (f->flags & SWRO_NO_COLOR) return;
+    float c[3];
+    for (int k = 0; k < 3; k++)                                   /* :266 */
+        c[k] = t->col[0][k] * w0 + t->col[1][k] * w1 + t->col[2][k] * w2;
+    uint8_t* p = f->color + at * 4;                               /* Pixel(float3:) :126-128 */
+    p[0] = swro_quantise(c[2]);  /* b */
+    p[1] = swro_quantise(c[1]);  /* g */
+    p[2] = swro_quantise(c[0]);  /* r */
+    p[3] = swro_quantise(1.0f);  /* a */
+}
+
+/* draw(triangle:colorBuffer:depthBuffer:) (:238-287); input already transformed. */
+static void draw_triangle(frame_t* f, tri_t* t) {
+    /* :271 sorted { $0.xyz.y < $1.xyz.y } — stable 3-element insertion sort on FLOAT y */
+    int ord[3] = {0, 1, 2};
+    for (int i = 1; i < 3; i++)
+        for (int j = i; j > 0 && t->sy[ord[j]] < t->sy[ord[j - 1]]; j--) {
+            int tmp = ord[j]; ord[j] = ord[j - 1]; ord[j - 1] = tmp;
+        }
+    int64_t left[6], right[4];
+    for (int k = 0; k < 3; k++) { left[2 * k] = t->ix[ord[k]]; left[2 * k + 1] = t->iy[ord[k]]; }
+    right[0] = left[0]; right[1] = left[1]; right[2] = left[4]; right[3] = left[5];  /* :272-273 */
+
+    float tinv[4];
+    const float* hoisted = NULL;
+    if (f->flags & SWRO_TINV_PER_TRIANGLE) {
+        float cfx = (float)t->ix[2] + 0.5f, cfy = (float)t->iy[2] + 0.5f;
+        float m00 = ((float)t->ix[0] + 0.5f) - cfx, m10 = ((float)t->iy[0] + 0.5f) - cfy;
+        float m01 = ((float)t->ix[1] + 0.5f) - cfx, m11 = ((float)t->iy[1] + 0.5f) - cfy;
+        float det = m00 * m11 - m01 * m10;
+        if (f->flags & SWRO_INV_RCP) {
+            float r = 1.0f / det;
+            tinv[0] = m11 * r; tinv[1] = -m01 * r; tinv[2] = -m10 * r; tinv[3] = m00 * r;
+        } else {
+            tinv[0] = m11 / det; tinv[1] = -m01 / det; tinv[2] = -m10 / det; tinv[3] = m00 / det;
+        }
+        hoisted = tinv;
+    }
+
+    int64_t y0 = left[1], y1 = left[5];          /* :275 sorted.first!.y ... sorted.last!.y */
+    int unclamped = (f->flags & SWRO_UNCLAMPED) != 0;
+    if (!unclamped) {                             /* off-screen rows are no-ops (:246-250) */
+        y0 = y0 < f->row_begin ? f->row_begin : y0;
+        y1 = y1 > f->row_end - 1 ? f->row_end - 1 : y1;
+    }
+    for (int64_t y = y0; y <= y1; y++) {
+        int64_t lx = swro_interpolate(left, 3, y);    /* :276 */
+        int64_t rx = swro_interpolate(right, 2, y);   /* :277 */
+        if (lx > rx) { int64_t tmp = lx; lx = rx; rx = tmp; }   /* :278-280 */
+        if (!unclamped) { lx = lx < 0 ? 0 : lx; rx = rx > f->W - 1 ? f->W - 1 : rx; }
+        for (int64_t x = lx; x <= rx; x++) set_pixel(f, t, x, y, hoisted);   /* :281-283 */
+    }
+}
+
+int swro_render(uint8_t* color, float* depth, int64_t W, int64_t H,
+                const swro_vertex* vertices, int64_t vertex_count,
+                const int64_t* indices, int64_t index_count,
+                const float M[16], uint32_t flags,
+                int64_t row_begin, int64_t row_end, swro_stats* stats) {
+    if (!depth || W <= 0 || H <= 0 || !M) return -1;
+    if (!(flags & SWRO_NO_COLOR) && !color) return -1;
+    if (index_count < 0 || vertex_count < 0) return -1;
+    if (index_count > 0 && (!indices || !vertices)) return -1;
+    if (index_count % 3 != 0) return -2;                          /* :209 */
+    if (row_begin < 0 || row_end > H || row_begin > row_end) return -1;
+    for (int64_t i = 0; i < index_count; i++)
+        if (indices[i] < 0 || indices[i] >= vertex_count) return -3;
+
+    frame_t f;
+    memset(&f, 0, sizeof f);
+    f.color = color; f.depth = depth; f.W = W; f.H = H;
+    f.row_begin = row_begin; f.row_end = row_end; f.flags = flags;
+
+    /* clear (:205-206, :232-236) — only this band's rows */
+    if (!(flags & SWRO_NO_COLOR))
+        memset(color + (size_t)row_begin * (size_t)W * 4, 0, (size_t)(row_end - row_begin) * (size_t)W * 4);
+    for (int64_t i = row_begin * W; i < row_end * W; i++) depth[i] = INFINITY;
+
+    float fw = (float)W, fh = (float)H;
+    int64_t nprim = index_count / 3;                              /* :221 */
+    for (int64_t p = 0; p < nprim; p++) {                         /* :222 in index order */
+        tri_t t;
+        int ok = 1;
+        for (int k = 0; k < 3; k++) {
+            const swro_vertex* v = &vertices[indices[3 * p + k]]; /* :223-227 */
+            /* Vertex.apply(transform:) (:159-163): xyzw = M * (x,y,z,1) accumulated column by
+             * column (col0*x, + col1*y, + col2*z, + col3*1); xyz / w */
+            float x = v->xyz[0], y = v->xyz[1], z = v->xyz[2];
+            float r[4];
+            for (int c = 0; c < 4; c++) {
+                float a = M[0 + c] * x;
+                a = a + M[4 + c] * y;
+                a = a + M[8 + c] * z;
+                a = a + M[12 + c] * 1.0f;
+                r[c] = a;
+            }
+            float nx = r[0] / r[3], ny = r[1] / r[3], nz = r[2] / r[3];
+            /* convertedToScreen (:165-171): uv = xy*(0.5,-0.5)+0.5 ; xy = uv*(W,H) (the
+             * .rounded() at :168 applies to the (W,H) constant: a no-op) */
+            float u = nx * 0.5f + 0.5f;
+            float w = ny * -0.5f + 0.5f;
+            t.sx[k] = u * fw;
+            t.sy[k] = w * fh;
+            t.sz[k] = nz;
+            t.col[k][0] = v->color[0]; t.col[k][1] = v->color[1]; t.col[k][2] = v->color[2];
+            if (!(fabsf(t.sx[k]) < COORD_LIMIT) || !(fabsf(t.sy[k]) < COORD_LIMIT)) { ok = 0; }
+            else { t.ix[k] = (int64_t)t.sx[k]; t.iy[k] = (int64_t)t.sy[k]; }   /* :251 truncation */
+        }
+        if (ok) {
+            float cfx = (float)t.ix[2] + 0.5f, cfy = (float)t.iy[2] + 0.5f;
+            float m00 = ((float)t.ix[0] + 0.5f) - cfx, m10 = ((float)t.iy[0] + 0.5f) - cfy;
+            float m01 = ((float)t.ix[1] + 0.5f) - cfx, m11 = ((float)t.iy[1] + 0.5f) - cfy;
+            float det = m00 * m11 - m01 * m10;
+            if (!(det != 0.0f) || !isfinite(det)) ok = 0;
+        }
+        if (!ok) { f.st.triangles_skipped++; continue; }
+        f.st.triangles_drawn++;
+        draw_triangle(&f, &t);                                    /* :228 */
+    }
+    if (stats) *stats = f.st;
+    return 0;
+}

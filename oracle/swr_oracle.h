@@ -1,0 +1,65 @@
+/*
+ * swr_oracle.h — CPU restatement of the reference's CPU triangle path.  TEST INFRASTRUCTURE.
+ *
+ * PARITY UNPINNED: the reference (zhvrnkov/software-renderer) ships no tests, golden images
+ * or fixtures, cannot be compiled here (Swift + Apple-only `simd`/`Metal` imports, no swift
+ * toolchain), and its float 2x2 `inverse` / 4x4 `*` come from Apple's closed `simd` module.
+ * This file follows the source text of renderer/Renderer.swift operation by operation; it is
+ * pinned only by the hand-derived known answers of SURVEY.md Appendix C and by an independent
+ * NumPy restatement (oracle/swr_oracle_np.py).
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library,
+ * and only as the checker / the reported CPU baseline.  The product (libswr_hip.so) never
+ * links, loads or calls it.
+ */
+#ifndef SWR_ORACLE_H_
+#define SWR_ORACLE_H_
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Same layout as swr_vertex (Renderer.swift:154-157). */
+typedef struct swro_vertex {
+    float xyz[4];
+    float color[4];
+} swro_vertex;
+
+enum {
+    SWRO_DEPTH_TEST = 1u << 0,  /* restore Renderer.swift:257-261 */
+    SWRO_NO_COLOR   = 1u << 1,  /* depth-only: colour image untouched */
+    /* oracle-only switches */
+    SWRO_INV_RCP    = 1u << 8,  /* 2x2 inverse as adj * (1/det) instead of adj / det */
+    SWRO_UNCLAMPED  = 1u << 9,  /* iterate rows/pixels exactly as Renderer.swift:275-283 does
+                                   (off-screen included) and reject per pixel (:246-250) */
+    SWRO_TINV_PER_TRIANGLE = 1u << 10 /* hoist T() out of the pixel loop (same values; the
+                                   reference recomputes it per pixel, Renderer.swift:251-252) */
+};
+
+typedef struct swro_stats {
+    int64_t fragments;        /* setPixel calls that passed the bounds check */
+    int64_t fragments_written;/* ... that also passed the z-test (== fragments when off) */
+    int64_t triangles_drawn;
+    int64_t triangles_skipped;/* non-finite / out-of-range / det == 0 (documented deviation) */
+} swro_stats;
+
+/* Renderer.render(renderPass:) restricted to rows [row_begin,row_end) of the W x H images.
+ * color: W*H*4 bytes BGRA (may be NULL with SWRO_NO_COLOR); depth: W*H floats.
+ * Returns 0, or a negative code with the same meaning as swr.h's. */
+int swro_render(uint8_t* color, float* depth, int64_t W, int64_t H,
+                const swro_vertex* vertices, int64_t vertex_count,
+                const int64_t* indices, int64_t index_count,
+                const float transform[16], uint32_t flags,
+                int64_t row_begin, int64_t row_end, swro_stats* stats);
+
+/* Renderer.interpolate(values:t:) (Renderer.swift:467-494), exposed for unit tests.
+ * pts = n (x,y) pairs, n in {2,3}. */
+int64_t swro_interpolate(const int64_t* pts_xy, int n, int64_t t);
+
+/* Pixel.floats channel quantiser (Renderer.swift:116-124). */
+uint8_t swro_quantise(float v);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

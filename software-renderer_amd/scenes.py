@@ -1,0 +1,241 @@
+"""Synthetic scenes for the BASELINE.json configs (inputs only — no rendering here).
+
+The reference ships no meshes (its demo mesh is a ModelIO-generated sphere, App.swift:124) and
+there is no network, so every config is procedural:
+
+  cfg1  one flat-shaded triangle, 256x256, identity transform            (KAT)
+  cfg2  "teapot-scale": closed torus, 6 320 triangles, Gouraud, 1920x1080
+  cfg3  "bunny-scale":  closed torus, 69 451 triangles, z-test, 3840x2160
+  cfg4  1 000 000 independent random triangles, z-test, 3840x2160        (headline)
+  cfg5  "Sponza-scale": 262 144 triangles (box interior grid), 7680x4320
+
+Random numbers are SplitMix64 -> 24-bit mantissa floats, seed 0x5EED0000 + config id, pure
+integer / IEEE arithmetic (no libm), so a scene is bit-reproducible on any host.
+
+Vertex layout = swr_vertex (Renderer.swift:154-157): float32[N, 8] = xyz, pad, rgb, pad.
+Indices = int64 (Swift Int, Renderer.swift:196).  Transform = float32[16] column-major.
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import numpy as np
+
+_GAMMA = np.uint64(0x9E3779B97F4A7C15)
+_M1 = np.uint64(0xBF58476D1CE4E5B9)
+_M2 = np.uint64(0x94D049BB133111EB)
+
+FLAG_DEPTH_TEST = 1
+FLAG_NO_COLOR = 2
+
+
+def splitmix64(seed: int, n: int, offset: int = 0) -> np.ndarray:
+    """n outputs of SplitMix64 seeded with `seed`, starting at draw number `offset`."""
+    with np.errstate(over="ignore"):
+        i = np.arange(offset + 1, offset + n + 1, dtype=np.uint64)
+        z = np.uint64(seed) + i * _GAMMA
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform01(seed: int, n: int, offset: int = 0) -> np.ndarray:
+    """float32 in [0,1) with 24 random mantissa bits."""
+    z = splitmix64(seed, n, offset)
+    return ((z >> np.uint64(40)).astype(np.float32)) * np.float32(1.0 / 16777216.0)
+
+
+@dataclass
+class Scene:
+    name: str
+    width: int
+    height: int
+    vertices: np.ndarray            # float32 [nv, 8]
+    indices: np.ndarray             # int64   [3*ntri]
+    transform: np.ndarray           # float32 [16], column-major
+    flags: int = 0
+    meta: dict = field(default_factory=dict)
+
+    @property
+    def triangles(self) -> int:
+        return int(self.indices.size // 3)
+
+
+def identity() -> np.ndarray:
+    return np.eye(4, dtype=np.float32).T.reshape(16).copy()
+
+
+def pack_vertices(xyz: np.ndarray, rgb: np.ndarray) -> np.ndarray:
+    v = np.zeros((xyz.shape[0], 8), dtype=np.float32)
+    v[:, 0:3] = xyz
+    v[:, 4:7] = rgb
+    return v
+
+
+def _quat(angle: float, axis) -> np.ndarray:
+    ax = np.asarray(axis, dtype=np.float64)
+    ax = ax / np.linalg.norm(ax)
+    s = math.sin(angle / 2.0)
+    return np.array([ax[0] * s, ax[1] * s, ax[2] * s, math.cos(angle / 2.0)])
+
+
+def _quat_mul(a, b):
+    ax, ay, az, aw = a
+    bx, by, bz, bw = b
+    return np.array([
+        aw * bx + ax * bw + ay * bz - az * by,
+        aw * by - ax * bz + ay * bw + az * bx,
+        aw * bz + ax * by - ay * bx + az * bw,
+        aw * bw - ax * bx - ay * by - az * bz,
+    ])
+
+
+def _quat_matrix(q) -> np.ndarray:
+    x, y, z, w = q
+    return np.array([
+        [1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+        [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+        [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)],
+    ])
+
+
+def app_transform(time: float, scale: float = 2.0) -> np.ndarray:
+    """projection * Transform(scale, rotation(time), translation (0,0,1)).matrix — the matrix
+    the app builds every frame (App.swift:169-183).  Returned column-major float32[16]."""
+    q = _quat_mul(_quat(time, (1.0, 1.0, 0.0)), _quat(0.5 * time, (0.0, 0.0, 1.0)))
+    m = np.eye(4)
+    m[:3, :3] = _quat_matrix(q) * scale          # rotation * scale
+    m[:3, 3] = (0.0, 0.0, 1.0)                   # translation
+    p = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 1, 1]], dtype=np.float64)
+    full = (p @ m).astype(np.float32)
+    return np.ascontiguousarray(full.T).reshape(16)   # column-major
+
+
+def torus_mesh(nu: int, nv: int, major: float, minor: float):
+    """Closed torus: nu*nv vertices, 2*nu*nv triangles; colour = |normal| (App.swift:133)."""
+    u = (np.arange(nu, dtype=np.float64) / nu) * 2 * math.pi
+    v = (np.arange(nv, dtype=np.float64) / nv) * 2 * math.pi
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    cx, sx = np.cos(uu), np.sin(uu)
+    cv, sv = np.cos(vv), np.sin(vv)
+    pos = np.stack([(major + minor * cv) * cx, (major + minor * cv) * sx, minor * sv], axis=-1)
+    nrm = np.stack([cv * cx, cv * sx, sv], axis=-1)
+    xyz = pos.reshape(-1, 3).astype(np.float32)
+    rgb = np.abs(nrm).reshape(-1, 3).astype(np.float32)
+    i = np.arange(nu)[:, None]
+    j = np.arange(nv)[None, :]
+    a = (i * nv + j)
+    b = (((i + 1) % nu) * nv + j)
+    c = (((i + 1) % nu) * nv + (j + 1) % nv)
+    d = (i * nv + (j + 1) % nv)
+    tris = np.stack([np.stack([a, b, c], -1), np.stack([a, c, d], -1)], axis=2)  # [nu,nv,2,3]
+    idx = tris.reshape(-1).astype(np.int64)
+    return xyz, rgb, idx
+
+
+# ---------------------------------------------------------------------------------------------
+def cfg1_triangle(gouraud: bool = False) -> Scene:
+    """one triangle, identity transform, 256x256."""
+    xyz = np.array([[0.0, 0.5, 0.5], [0.5, -0.5, 0.5], [-0.5, -0.5, 0.5]], dtype=np.float32)
+    if gouraud:
+        rgb = np.eye(3, dtype=np.float32)
+    else:
+        rgb = np.tile(np.array([1.0, 0.5, 0.25], dtype=np.float32), (3, 1))
+    return Scene("cfg1_triangle" + ("_gouraud" if gouraud else ""), 256, 256,
+                 pack_vertices(xyz, rgb), np.arange(3, dtype=np.int64), identity(), 0)
+
+
+def cfg2_teapot_scale(width: int = 1920, height: int = 1080, time: float = 1.0,
+                      nu: int = 40, nv: int = 79) -> Scene:
+    xyz, rgb, idx = torus_mesh(nu, nv, 0.25, 0.11)
+    return Scene("cfg2_teapot_scale", width, height, pack_vertices(xyz, rgb), idx,
+                 app_transform(time), 0, {"mesh": f"torus {nu}x{nv}"})
+
+
+def cfg3_bunny_scale(width: int = 3840, height: int = 2160, time: float = 1.0,
+                     nu: int = 194, nv: int = 179, ntri: int | None = 69451) -> Scene:
+    xyz, rgb, idx = torus_mesh(nu, nv, 0.25, 0.11)
+    if ntri is not None:
+        idx = idx[: 3 * ntri].copy()
+    return Scene("cfg3_bunny_scale", width, height, pack_vertices(xyz, rgb), idx,
+                 app_transform(time), FLAG_DEPTH_TEST, {"mesh": f"torus {nu}x{nv}"})
+
+
+def _disc_offsets(seed: int, n: int, offset: int, tries: int = 8) -> np.ndarray:
+    """n points uniform in the unit disc by rejection from the square, using only IEEE
+    arithmetic: candidate k of point i comes from draws (2*(i*tries+k), +1)."""
+    u = uniform01(seed, 2 * n * tries, offset).reshape(n, tries, 2)
+    c = u * np.float32(2.0) - np.float32(1.0)
+    inside = (c[..., 0] * c[..., 0] + c[..., 1] * c[..., 1]) <= np.float32(1.0)
+    first = np.argmax(inside, axis=1)
+    pick = c[np.arange(n), first]
+    none = ~inside.any(axis=1)
+    pick[none] = 0.0
+    return pick
+
+
+def cfg4_soup(ntri: int = 1_000_000, width: int = 3840, height: int = 2160,
+              r_ndc: float = 0.008, depth_only: bool = True, seed: int = 0x5EED0004) -> Scene:
+    """Independent random triangles (3 unshared vertices each): centre uniform in
+    [-0.98,0.98]^2, vertex offsets uniform in a disc of radius r_ndc, z uniform [0.05,0.95],
+    colours uniform, identity transform (w = 1), z-test ON."""
+    centre = uniform01(seed, 2 * ntri, 0).reshape(ntri, 2) * np.float32(1.96) - np.float32(0.98)
+    off = _disc_offsets(seed, 3 * ntri, 2 * ntri).reshape(ntri, 3, 2) * np.float32(r_ndc)
+    base = 2 * ntri + 2 * 3 * ntri * 8
+    z = uniform01(seed, 3 * ntri, base).reshape(ntri, 3) * np.float32(0.9) + np.float32(0.05)
+    rgb = uniform01(seed, 9 * ntri, base + 3 * ntri).reshape(3 * ntri, 3)
+    xyz = np.empty((ntri, 3, 3), dtype=np.float32)
+    xyz[:, :, 0:2] = centre[:, None, :] + off
+    xyz[:, :, 2] = z
+    flags = FLAG_DEPTH_TEST | (FLAG_NO_COLOR if depth_only else 0)
+    return Scene("cfg4_soup", width, height, pack_vertices(xyz.reshape(-1, 3), rgb),
+                 np.arange(3 * ntri, dtype=np.int64), identity(), flags,
+                 {"r_ndc": r_ndc, "seed": seed})
+
+
+def cfg5_sponza_scale(width: int = 7680, height: int = 4320, nx: int = 512, ny: int = 256) -> Scene:
+    """Two facing grids of quads (a 'box interior' front/back wall pair): nx*ny*2 triangles
+    per wall pair = 262 144 for 512x256."""
+    gx = np.linspace(-0.95, 0.95, nx // 2 + 1, dtype=np.float64)
+    gy = np.linspace(-0.95, 0.95, ny + 1, dtype=np.float64)
+    xx, yy = np.meshgrid(gx, gy, indexing="ij")
+    verts, cols, idxs = [], [], []
+    base = 0
+    for wall, zval in enumerate((0.8, 0.3)):
+        zz = zval + 0.1 * np.sin(3.0 * xx) * np.cos(2.0 * yy)
+        xyz = np.stack([xx * (1.0 if wall == 0 else 0.6), yy * (1.0 if wall == 0 else 0.6), zz], -1).reshape(-1, 3)
+        rgb = np.stack([0.5 + 0.5 * np.sin(7 * xx + wall), 0.5 + 0.5 * np.cos(5 * yy), np.full_like(xx, 0.3 + 0.4 * wall)], -1).reshape(-1, 3)
+        ncol = ny + 1
+        i = np.arange(nx // 2)[:, None]
+        j = np.arange(ny)[None, :]
+        a = i * ncol + j
+        b = (i + 1) * ncol + j
+        c = (i + 1) * ncol + j + 1
+        d = i * ncol + j + 1
+        tris = np.stack([np.stack([a, b, c], -1), np.stack([a, c, d], -1)], axis=2).reshape(-1) + base
+        verts.append(xyz.astype(np.float32)); cols.append(rgb.astype(np.float32)); idxs.append(tris.astype(np.int64))
+        base += xyz.shape[0]
+    return Scene("cfg5_sponza_scale", width, height,
+                 pack_vertices(np.concatenate(verts), np.concatenate(cols)),
+                 np.concatenate(idxs), identity(), FLAG_DEPTH_TEST, {})
+
+
+def random_soup(ntri: int, width: int, height: int, seed: int, r_ndc: float = 0.1,
+                flags: int = 0, margin: float = 1.2, shared: bool = False) -> Scene:
+    """General random triangles for parity tests; with margin > 1 some triangles straddle or
+    leave the screen (exercises the per-pixel scissor, Renderer.swift:246-250)."""
+    centre = (uniform01(seed, 2 * ntri, 0).reshape(ntri, 2) * np.float32(2.0) - np.float32(1.0)) * np.float32(margin)
+    off = (uniform01(seed, 6 * ntri, 2 * ntri).reshape(ntri, 3, 2) * np.float32(2.0) - np.float32(1.0)) * np.float32(r_ndc)
+    z = uniform01(seed, 3 * ntri, 8 * ntri).reshape(ntri, 3)
+    rgb = uniform01(seed, 9 * ntri, 11 * ntri).reshape(3 * ntri, 3) * np.float32(1.2) - np.float32(0.1)
+    xyz = np.empty((ntri, 3, 3), dtype=np.float32)
+    xyz[:, :, 0:2] = centre[:, None, :] + off
+    xyz[:, :, 2] = z
+    idx = np.arange(3 * ntri, dtype=np.int64)
+    if shared and ntri > 1:
+        # re-use vertices between triangles (exercise the index path)
+        idx = (splitmix64(seed ^ 0xABCDEF, 3 * ntri) % np.uint64(3 * ntri)).astype(np.int64)
+    return Scene(f"soup_{ntri}_{seed:x}", width, height, pack_vertices(xyz.reshape(-1, 3), rgb),
+                 idx, identity(), flags, {})

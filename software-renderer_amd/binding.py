@@ -1,0 +1,226 @@
+"""ctypes binding of include/swr.h (plumbing for tests / bench; the product is the .so)."""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_PKG, "lib", "libswr_hip.so")
+
+FLAG_DEPTH_TEST = 1
+FLAG_NO_COLOR = 2
+
+# every symbol include/swr.h declares (checked by tests/test_abi.py)
+ABI_SYMBOLS = [
+    "swr_abi_version", "swr_version", "swr_context_create", "swr_context_destroy", "swr_last_error",
+    "swr_render", "swr_scene_upload", "swr_target_set", "swr_draw", "swr_sync", "swr_read_color",
+    "swr_read_depth", "swr_timing_enable", "swr_get_timings", "swr_tile_rows", "swr_tile_cols",
+    "swr_band_rows",
+]
+
+
+class SwrError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"swr error {code}: {msg}")
+        self.code = code
+
+
+class RenderPass(ctypes.Structure):
+    """swr_render_pass (include/swr.h) == RenderPass (Renderer.swift:191-200)."""
+    _fields_ = [
+        ("color", ctypes.c_void_p), ("depth", ctypes.c_void_p),
+        ("width", ctypes.c_int64), ("height", ctypes.c_int64),
+        ("color_bytes_per_row", ctypes.c_int64), ("depth_bytes_per_row", ctypes.c_int64),
+        ("vertices", ctypes.c_void_p), ("vertex_count", ctypes.c_int64),
+        ("indices", ctypes.c_void_p), ("index_count", ctypes.c_int64),
+        ("primitive_type", ctypes.c_int32), ("flags", ctypes.c_uint32),
+        ("transform", ctypes.c_float * 16),
+    ]
+
+
+class Config(ctypes.Structure):
+    _fields_ = [("device", ctypes.c_int32), ("reserved", ctypes.c_uint32)]
+
+
+class Timings(ctypes.Structure):
+    _fields_ = [("setup_bin_ms", ctypes.c_float), ("scan_ms", ctypes.c_float),
+                ("scatter_ms", ctypes.c_float), ("raster_ms", ctypes.c_float),
+                ("total_ms", ctypes.c_float), ("tile_pairs", ctypes.c_int64),
+                ("tiles", ctypes.c_int64), ("triangles", ctypes.c_int64)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+def library_path() -> str:
+    return _LIB
+
+
+def build(force: bool = False) -> str:
+    """hipcc --offload-arch=gfx950 build of the in-tree library (cross-compiles without a GPU)."""
+    srcs = [os.path.join(_PKG, "csrc", f) for f in os.listdir(os.path.join(_PKG, "csrc"))]
+    srcs.append(os.path.join(_PKG, "..", "include", "swr.h"))
+    stale = force or not os.path.exists(_LIB) or any(os.path.getmtime(s) > os.path.getmtime(_LIB) for s in srcs)
+    if stale:
+        subprocess.check_call(["make", "-C", _PKG, "-s", "lib/libswr_hip.so"])
+    return _LIB
+
+
+_lib = None
+
+
+def load_library():
+    """dlopen the product library; raises if it is not built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_LIB):
+        raise SwrError(-4, f"{_LIB} is not built; run `make -C software-renderer_amd` (hipcc, gfx950)")
+    L = ctypes.CDLL(_LIB)
+    vp, i64, i32, u32 = ctypes.c_void_p, ctypes.c_int64, ctypes.c_int32, ctypes.c_uint32
+    L.swr_abi_version.restype = ctypes.c_int
+    L.swr_version.restype = ctypes.c_char_p
+    L.swr_last_error.restype = ctypes.c_char_p
+    L.swr_last_error.argtypes = [vp]
+    L.swr_context_create.argtypes = [ctypes.POINTER(Config), ctypes.POINTER(vp)]
+    L.swr_context_destroy.argtypes = [vp]
+    L.swr_context_destroy.restype = None
+    L.swr_render.argtypes = [vp, ctypes.POINTER(RenderPass)]
+    L.swr_scene_upload.argtypes = [vp, vp, i64, vp, i64]
+    L.swr_target_set.argtypes = [vp, i64, i64, i64, i64]
+    L.swr_draw.argtypes = [vp, vp, u32]
+    L.swr_sync.argtypes = [vp]
+    L.swr_read_color.argtypes = [vp, vp]
+    L.swr_read_depth.argtypes = [vp, vp]
+    L.swr_timing_enable.argtypes = [vp, ctypes.c_int]
+    L.swr_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
+    L.swr_band_rows.argtypes = [i64, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    for name in ("swr_context_create", "swr_render", "swr_scene_upload", "swr_target_set", "swr_draw",
+                 "swr_sync", "swr_read_color", "swr_read_depth", "swr_timing_enable", "swr_get_timings",
+                 "swr_band_rows", "swr_tile_rows", "swr_tile_cols"):
+        getattr(L, name).restype = ctypes.c_int
+    _lib = L
+    return L
+
+
+def tile_shape():
+    L = load_library()
+    return L.swr_tile_cols(), L.swr_tile_rows()
+
+
+def band_rows(height: int, parts: int, part: int):
+    L = load_library()
+    a, b = ctypes.c_int64(), ctypes.c_int64()
+    rc = L.swr_band_rows(height, parts, part, ctypes.byref(a), ctypes.byref(b))
+    if rc:
+        raise SwrError(rc, "swr_band_rows: bad arguments")
+    return a.value, b.value
+
+
+class Context:
+    """swr_context: one per GPU / per caller thread (GpuRenderer instance, App.swift:149)."""
+
+    def __init__(self, device: int = -1):
+        self._L = load_library()
+        self._h = ctypes.c_void_p()
+        cfg = Config(device, 0)
+        rc = self._L.swr_context_create(ctypes.byref(cfg), ctypes.byref(self._h))
+        if rc:
+            raise SwrError(rc, (self._L.swr_last_error(None) or b"").decode())
+        self.width = self.height = 0
+        self.row_begin = self.row_end = 0
+
+    def close(self):
+        if self._h:
+            self._L.swr_context_destroy(self._h)
+            self._h = ctypes.c_void_p()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc: int):
+        if rc:
+            raise SwrError(rc, (self._L.swr_last_error(self._h) or b"").decode())
+
+    # -- resident path -------------------------------------------------------------------
+    def scene_upload(self, vertices: np.ndarray, indices: np.ndarray):
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 8)
+        i = np.ascontiguousarray(indices, dtype=np.int64).reshape(-1)
+        self._check(self._L.swr_scene_upload(self._h, v.ctypes.data, v.shape[0], i.ctypes.data, i.size))
+
+    def target_set(self, width: int, height: int, row_begin: int = 0, row_end: int | None = None):
+        if row_end is None:
+            row_end = height
+        self._check(self._L.swr_target_set(self._h, width, height, row_begin, row_end))
+        self.width, self.height, self.row_begin, self.row_end = width, height, row_begin, row_end
+
+    def draw(self, transform: np.ndarray, flags: int = 0):
+        m = np.ascontiguousarray(transform, dtype=np.float32).reshape(16)
+        self._check(self._L.swr_draw(self._h, m.ctypes.data, flags))
+
+    def sync(self):
+        self._check(self._L.swr_sync(self._h))
+
+    def read_color(self, out: np.ndarray | None = None) -> np.ndarray:
+        if out is None:
+            out = np.zeros((self.height, self.width, 4), dtype=np.uint8)
+        assert out.flags.c_contiguous and out.nbytes == self.width * self.height * 4
+        self._check(self._L.swr_read_color(self._h, out.ctypes.data))
+        return out
+
+    def read_depth(self, out: np.ndarray | None = None) -> np.ndarray:
+        if out is None:
+            out = np.zeros((self.height, self.width), dtype=np.float32)
+        assert out.flags.c_contiguous and out.nbytes == self.width * self.height * 4
+        self._check(self._L.swr_read_depth(self._h, out.ctypes.data))
+        return out
+
+    def timing_enable(self, on: bool = True):
+        self._check(self._L.swr_timing_enable(self._h, 1 if on else 0))
+
+    def timings(self) -> dict:
+        t = Timings()
+        self._check(self._L.swr_get_timings(self._h, ctypes.byref(t)))
+        return t.as_dict()
+
+    # -- one-shot path: Renderer.render(renderPass:) / GpuRenderer.render(renderPass:) -----
+    def render(self, vertices, indices, transform, width, height, flags=0, primitive_type=0,
+               color=None, depth=None):
+        v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 8)
+        i = np.ascontiguousarray(indices, dtype=np.int64).reshape(-1)
+        m = np.ascontiguousarray(transform, dtype=np.float32).reshape(16)
+        if color is None and not (flags & FLAG_NO_COLOR):
+            color = np.full((height, width, 4), 0xCD, dtype=np.uint8)
+        if depth is None:
+            depth = np.full((height, width), -123.0, dtype=np.float32)
+        rp = RenderPass()
+        rp.color = color.ctypes.data if color is not None else None
+        rp.depth = depth.ctypes.data
+        rp.width, rp.height = width, height
+        rp.color_bytes_per_row = width * 4
+        rp.depth_bytes_per_row = width * 4
+        rp.vertices, rp.vertex_count = v.ctypes.data, v.shape[0]
+        rp.indices, rp.index_count = i.ctypes.data, i.size
+        rp.primitive_type, rp.flags = primitive_type, flags
+        rp.transform = (ctypes.c_float * 16)(*m.tolist())
+        self._check(self._L.swr_render(self._h, ctypes.byref(rp)))
+        return color, depth
+
+
+def render(scene, extra_flags: int = 0, device: int = -1):
+    """Convenience: one-shot render of a scenes.Scene; returns (color, depth)."""
+    with Context(device) as ctx:
+        return ctx.render(scene.vertices, scene.indices, scene.transform, scene.width, scene.height,
+                          scene.flags | extra_flags)

@@ -1,0 +1,373 @@
+// swr_api.hip — the C-ABI of include/swr.h over the gfx950 kernels (swr_kernels.hip).
+//
+// Stands in for GpuRenderer.render(renderPass:) (renderer/GpuRenderer.swift:35-141): where the
+// reference allocates shared MTLBuffers, encodes one compute dispatch per triangle and blocks
+// twice per frame in scheduleAndWait, this context keeps scene, records, bins and the
+// framebuffer band resident in HBM and enqueues four kernels on one HIP stream per frame.
+// There is no CPU fallback: without a HIP device every computing entry point fails.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "swr_internal.h"
+
+using namespace swr;
+
+namespace {
+thread_local std::string g_create_error;
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+};
+}  // namespace
+
+struct swr_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // scene (RenderPass.vertices / .indices)
+    DevBuf vertices, indices, geo, col;
+    int64_t nv = 0, ni = 0;
+    bool has_scene = false;
+
+    // target band (RenderPass.colorBuffer / .depthBuffer)
+    Target tg{};
+    bool has_target = false;
+    DevBuf color, depth;
+    DevBuf tilebuf;            // [CNT_WORDS counters][tiles tile_count][tiles+1 tile_start]
+    DevBuf pair_tile, pair_slot, pair_prim, bins;
+    uint32_t capacity = 0;
+
+    uint32_t* h_counters = nullptr;   // pinned
+    // last draw (for the overflow redo and for swr_render)
+    float last_m[16]{};
+    uint32_t last_flags = 0;
+    bool draw_pending = false;
+
+    bool timing = false;
+    hipEvent_t ev[5]{};
+    bool ev_ok = false;
+    swr_timings last{};
+};
+
+namespace {
+
+int fail(swr_context* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                     \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess)                                                                  \
+            return fail(ctx, SWR_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), \
+                        __FILE__, __LINE__);                                                   \
+    } while (0)
+
+int ensure(swr_context* c, DevBuf& b, size_t bytes) {
+    if (bytes == 0) bytes = 16;
+    if (b.bytes >= bytes) return SWR_OK;
+    if (b.p) { HIP_TRY(c, hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    // grow geometrically so a slowly growing scene does not reallocate every frame
+    size_t want = bytes + bytes / 8;
+    hipError_t e = hipMalloc(&b.p, want);
+    if (e != hipSuccess) {
+        b.p = nullptr;
+        return fail(c, SWR_ERR_NOMEM, "hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+    }
+    b.bytes = want;
+    return SWR_OK;
+}
+
+int ensure_capacity(swr_context* c, uint32_t cap) {
+    if (cap <= c->capacity) return SWR_OK;
+    int rc;
+    if ((rc = ensure(c, c->pair_tile, (size_t)cap * 4))) return rc;
+    if ((rc = ensure(c, c->pair_slot, (size_t)cap * 4))) return rc;
+    if ((rc = ensure(c, c->pair_prim, (size_t)cap * 4))) return rc;
+    if ((rc = ensure(c, c->bins, (size_t)cap * 4))) return rc;
+    c->capacity = cap;
+    return SWR_OK;
+}
+
+inline int tiles_of(const Target& t) { return t.tiles_x * t.tiles_y; }
+
+DeviceFrame make_frame(swr_context* c, const float m[16], uint32_t flags) {
+    DeviceFrame f{};
+    f.vertices = (const swr_vertex*)c->vertices.p;
+    f.indices = (const int64_t*)c->indices.p;
+    f.vertex_count = c->nv;
+    f.ntri = c->ni / 3;
+    f.geo = (GeomRec*)c->geo.p;
+    f.col = (ColRec*)c->col.p;
+    uint32_t* tb = (uint32_t*)c->tilebuf.p;
+    f.counters = tb;
+    f.tile_count = tb + CNT_WORDS;
+    f.tile_start = tb + CNT_WORDS + tiles_of(c->tg);
+    f.pair_tile = (uint32_t*)c->pair_tile.p;
+    f.pair_slot = (uint32_t*)c->pair_slot.p;
+    f.pair_prim = (uint32_t*)c->pair_prim.p;
+    f.bins = (uint32_t*)c->bins.p;
+    f.capacity = c->capacity;
+    f.color = (uint8_t*)c->color.p;
+    f.depth = (float*)c->depth.p;
+    f.tg = c->tg;
+    memcpy(f.m, m, sizeof f.m);
+    f.flags = flags;
+    return f;
+}
+
+int enqueue_frame(swr_context* c) {
+    DeviceFrame f = make_frame(c, c->last_m, c->last_flags);
+    const size_t zero_bytes = (size_t)(CNT_WORDS + tiles_of(c->tg)) * 4;
+    HIP_TRY(c, hipMemsetAsync(c->tilebuf.p, 0, zero_bytes, c->stream));
+    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    launch_setup_bin(f, c->stream);
+    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    launch_scan(f, c->stream);
+    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    launch_scatter(f, c->stream);
+    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+    launch_raster(f, c->stream);
+    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->h_counters, f.counters, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
+    c->draw_pending = true;
+    return SWR_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int swr_abi_version(void) { return SWR_ABI_VERSION; }
+const char* swr_version(void) { return "swr-hip gfx950 0.1 (tile 64x32, wave64 LDS visibility keys)"; }
+int swr_tile_rows(void) { return TILE_H; }
+int swr_tile_cols(void) { return TILE_W; }
+
+const char* swr_last_error(const swr_context* ctx) {
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int swr_band_rows(int64_t height, int32_t parts, int32_t part, int64_t* row_begin, int64_t* row_end) {
+    if (height <= 0 || parts <= 0 || part < 0 || part >= parts || !row_begin || !row_end)
+        return SWR_ERR_BAD_ARG;
+    const int64_t trows = (height + TILE_H - 1) / TILE_H;
+    const int64_t t0 = trows * part / parts, t1 = trows * (part + 1) / parts;
+    *row_begin = std::min<int64_t>(t0 * TILE_H, height);
+    *row_end = std::min<int64_t>(t1 * TILE_H, height);
+    return SWR_OK;
+}
+
+int swr_context_create(const swr_config* cfg, swr_context** out) {
+    if (!out) return fail(nullptr, SWR_ERR_BAD_ARG, "swr_context_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, SWR_ERR_HIP, "no HIP device (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    int dev = cfg ? cfg->device : -1;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) return fail(nullptr, SWR_ERR_BAD_ARG, "device %d out of range (%d devices)", dev, ndev);
+    swr_context* c = new swr_context();
+    c->device = dev;
+    if ((e = hipSetDevice(dev)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipHostMalloc((void**)&c->h_counters, CNT_WORDS * 4, hipHostMallocDefault)) != hipSuccess) {
+        int rc = fail(nullptr, SWR_ERR_HIP, "context init failed: %s", hipGetErrorString(e));
+        delete c;
+        return rc;
+    }
+    memset(c->h_counters, 0, CNT_WORDS * 4);
+    for (int i = 0; i < 5; i++) hipEventCreate(&c->ev[i]);
+    c->ev_ok = true;
+    *out = c;
+    return SWR_OK;
+}
+
+void swr_context_destroy(swr_context* c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->geo, &c->col, &c->color, &c->depth, &c->tilebuf,
+                      &c->pair_tile, &c->pair_slot, &c->pair_prim, &c->bins};
+    for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
+    if (c->h_counters) hipHostFree(c->h_counters);
+    if (c->ev_ok) for (int i = 0; i < 5; i++) hipEventDestroy(c->ev[i]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_count,
+                     const int64_t* indices, int64_t index_count) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    if (vertex_count < 0 || index_count < 0 || (index_count > 0 && (!indices || !vertices)))
+        return fail(c, SWR_ERR_BAD_ARG, "swr_scene_upload: bad vertex/index arguments");
+    if (index_count % 3 != 0)                                     // assert, Renderer.swift:209
+        return fail(c, SWR_ERR_INDEX_COUNT, "index_count %lld is not a multiple of 3", (long long)index_count);
+    if (index_count / 3 >= 0xFFFFFFFFll)
+        return fail(c, SWR_ERR_UNSUPPORTED, "more than 2^32-2 primitives");
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->has_scene = false;
+    c->draw_pending = false;
+    int rc;
+    if ((rc = ensure(c, c->vertices, (size_t)vertex_count * sizeof(swr_vertex)))) return rc;
+    if ((rc = ensure(c, c->indices, (size_t)index_count * 8))) return rc;
+    if ((rc = ensure(c, c->geo, (size_t)(index_count / 3) * sizeof(GeomRec)))) return rc;
+    if ((rc = ensure(c, c->col, (size_t)(index_count / 3) * sizeof(ColRec)))) return rc;
+    if ((rc = ensure(c, c->tilebuf, (size_t)(CNT_WORDS + 2 * std::max(1, tiles_of(c->tg)) + 1) * 4))) return rc;
+    if (vertex_count)
+        HIP_TRY(c, hipMemcpyAsync(c->vertices.p, vertices, (size_t)vertex_count * sizeof(swr_vertex),
+                                  hipMemcpyHostToDevice, c->stream));
+    if (index_count)
+        HIP_TRY(c, hipMemcpyAsync(c->indices.p, indices, (size_t)index_count * 8, hipMemcpyHostToDevice, c->stream));
+    // index range check (Swift array subscript would trap, Renderer.swift:226)
+    HIP_TRY(c, hipMemsetAsync(c->tilebuf.p, 0, CNT_WORDS * 4, c->stream));
+    launch_validate_indices((const int64_t*)c->indices.p, index_count, vertex_count, (uint32_t*)c->tilebuf.p, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->tilebuf.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (c->h_counters[CNT_BAD_INDEX])
+        return fail(c, SWR_ERR_INDEX_RANGE, "an index is outside [0, %lld)", (long long)vertex_count);
+    c->nv = vertex_count;
+    c->ni = index_count;
+    c->has_scene = true;
+    const uint64_t want = (uint64_t)(index_count / 3) * 2 + 65536;
+    return ensure_capacity(c, (uint32_t)std::min<uint64_t>(want, 0xFFFFFFF0ull));
+}
+
+int swr_target_set(swr_context* c, int64_t width, int64_t height, int64_t row_begin, int64_t row_end) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    if (width <= 0 || height <= 0 || width > (1 << 24) || height > (1 << 24))
+        return fail(c, SWR_ERR_BAD_ARG, "bad framebuffer size %lldx%lld", (long long)width, (long long)height);
+    if (row_begin < 0 || row_end > height || row_begin > row_end || (row_begin % TILE_H) != 0)
+        return fail(c, SWR_ERR_BAD_ARG, "bad band [%lld,%lld): row_begin must be a multiple of %d",
+                    (long long)row_begin, (long long)row_end, TILE_H);
+    HIP_TRY(c, hipSetDevice(c->device));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->draw_pending = false;
+    Target t;
+    t.width = (int32_t)width; t.height = (int32_t)height;
+    t.row_begin = (int32_t)row_begin; t.row_end = (int32_t)row_end;
+    t.tiles_x = (int32_t)((width + TILE_W - 1) / TILE_W);
+    t.tiles_y = (int32_t)((row_end - row_begin + TILE_H - 1) / TILE_H);
+    const size_t px = (size_t)width * (size_t)(row_end - row_begin);
+    int rc;
+    if ((rc = ensure(c, c->color, px * 4))) return rc;
+    if ((rc = ensure(c, c->depth, px * 4))) return rc;
+    if ((rc = ensure(c, c->tilebuf, (size_t)(CNT_WORDS + 2 * std::max(1, tiles_of(t)) + 1) * 4))) return rc;
+    c->tg = t;
+    c->has_target = true;
+    return SWR_OK;
+}
+
+int swr_draw(swr_context* c, const float transform[16], uint32_t flags) {
+    if (!c || !transform) return SWR_ERR_BAD_ARG;
+    if (!c->has_scene || !c->has_target)
+        return fail(c, SWR_ERR_NO_SCENE, "swr_draw needs swr_scene_upload and swr_target_set first");
+    if (flags & ~(uint32_t)(SWR_FLAG_DEPTH_TEST | SWR_FLAG_NO_COLOR))
+        return fail(c, SWR_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
+    HIP_TRY(c, hipSetDevice(c->device));
+    memcpy(c->last_m, transform, sizeof c->last_m);
+    c->last_flags = flags;
+    return enqueue_frame(c);
+}
+
+int swr_sync(swr_context* c) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    HIP_TRY(c, hipSetDevice(c->device));
+    for (int attempt = 0; attempt < 8; attempt++) {
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if (!c->draw_pending) return SWR_OK;
+        const uint32_t pairs = c->h_counters[CNT_PAIRS];
+        if (pairs <= c->capacity) {
+            c->draw_pending = false;
+            c->last.tile_pairs = pairs;
+            c->last.tiles = tiles_of(c->tg);
+            c->last.triangles = c->ni / 3;
+            if (c->timing) {
+                float ms[5] = {0, 0, 0, 0, 0};
+                hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]);
+                hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]);
+                hipEventElapsedTime(&ms[2], c->ev[2], c->ev[3]);
+                hipEventElapsedTime(&ms[3], c->ev[3], c->ev[4]);
+                hipEventElapsedTime(&ms[4], c->ev[0], c->ev[4]);
+                c->last.setup_bin_ms = ms[0]; c->last.scan_ms = ms[1]; c->last.scatter_ms = ms[2];
+                c->last.raster_ms = ms[3]; c->last.total_ms = ms[4];
+            }
+            return SWR_OK;
+        }
+        // the (triangle,tile) pair list overflowed: grow and redraw the same frame
+        const uint64_t want = (uint64_t)pairs + pairs / 4 + 1024;
+        if (want > 0xFFFFFFF0ull) return fail(c, SWR_ERR_UNSUPPORTED, "too many (triangle,tile) pairs: %u", pairs);
+        int rc = ensure_capacity(c, (uint32_t)want);
+        if (rc) return rc;
+        if ((rc = enqueue_frame(c))) return rc;
+    }
+    return fail(c, SWR_ERR_HIP, "pair list kept overflowing");
+}
+
+int swr_read_color(swr_context* c, void* dst) {
+    if (!c || !dst) return SWR_ERR_BAD_ARG;
+    int rc = swr_sync(c);
+    if (rc) return rc;
+    const size_t row = (size_t)c->tg.width * 4;
+    const size_t rows = (size_t)(c->tg.row_end - c->tg.row_begin);
+    if (rows)
+        HIP_TRY(c, hipMemcpy((uint8_t*)dst + (size_t)c->tg.row_begin * row, c->color.p, rows * row, hipMemcpyDeviceToHost));
+    return SWR_OK;
+}
+
+int swr_read_depth(swr_context* c, float* dst) {
+    if (!c || !dst) return SWR_ERR_BAD_ARG;
+    int rc = swr_sync(c);
+    if (rc) return rc;
+    const size_t row = (size_t)c->tg.width * 4;
+    const size_t rows = (size_t)(c->tg.row_end - c->tg.row_begin);
+    if (rows)
+        HIP_TRY(c, hipMemcpy((uint8_t*)dst + (size_t)c->tg.row_begin * row, c->depth.p, rows * row, hipMemcpyDeviceToHost));
+    return SWR_OK;
+}
+
+int swr_timing_enable(swr_context* c, int enable) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    c->timing = enable != 0;
+    return SWR_OK;
+}
+
+int swr_get_timings(swr_context* c, swr_timings* out) {
+    if (!c || !out) return SWR_ERR_BAD_ARG;
+    int rc = swr_sync(c);
+    if (rc) return rc;
+    *out = c->last;
+    return SWR_OK;
+}
+
+int swr_render(swr_context* c, const swr_render_pass* p) {
+    if (!c || !p) return SWR_ERR_BAD_ARG;
+    if (p->primitive_type != SWR_PRIMITIVE_TRIANGLE)
+        return fail(c, SWR_ERR_UNSUPPORTED, "primitive type %d is not on the triangle hot path", p->primitive_type);
+    if (!p->depth || (!(p->flags & SWR_FLAG_NO_COLOR) && !p->color))
+        return fail(c, SWR_ERR_BAD_ARG, "swr_render: colour/depth image pointer is NULL");
+    int rc;
+    if ((rc = swr_scene_upload(c, p->vertices, p->vertex_count, p->indices, p->index_count))) return rc;
+    if ((rc = swr_target_set(c, p->width, p->height, 0, p->height))) return rc;
+    if ((rc = swr_draw(c, p->transform, p->flags))) return rc;
+    if (!(p->flags & SWR_FLAG_NO_COLOR) && (rc = swr_read_color(c, p->color))) return rc;
+    return swr_read_depth(c, p->depth);
+}
+
+}  // extern "C"

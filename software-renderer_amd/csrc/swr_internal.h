@@ -1,0 +1,81 @@
+// swr_internal.h — structures shared between the HIP kernels (swr_kernels.hip) and the C-ABI
+// host code (swr_api.hip).  Nothing here is part of the public boundary (include/swr.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/swr.h"
+
+namespace swr {
+
+// Screen-space tile owned by one workgroup of the raster kernel.  The per-pixel visibility
+// key tile (8 B/pixel) lives in LDS: 64x32 -> 16 KiB, i.e. up to 8 workgroups per CU by LDS.
+constexpr int TILE_W = 64;
+constexpr int TILE_H = 32;
+constexpr int RASTER_THREADS = 256;
+
+// Per-triangle record written by the setup kernel and gathered by the raster kernel.
+// 64 bytes = 4 x 16-byte loads.
+struct GeomRec {
+    int32_t ax, ay, bx, by;        // truncated screen vertices A,B (Renderer.swift:251)
+    int32_t cx, cy;                // C
+    uint32_t flags;                // GEOM_* below
+    uint32_t prim;                 // primitive index (kept for debugging / resolve)
+    float t00, t01, t10, t11;      // T() = inverse([A-C | B-C]) = adj / det (Renderer.swift:95-100)
+    float za, zb, zc;              // NDC z of a,b,c (Renderer.swift:254-256)
+    float pad;
+};
+static_assert(sizeof(GeomRec) == 64, "GeomRec must be 64 bytes");
+
+enum : uint32_t {
+    GEOM_VALID = 1u << 0,
+    GEOM_SMALL = 1u << 1,          // all |dx| < 2^15 and dy < 2^16: 32-bit span arithmetic is exact
+    GEOM_ORD_SHIFT = 2             // 3 x 2 bits: which of a,b,c is S0,S1,S2 of the y-sorted list (:271)
+};
+
+// Vertex colours of a,b,c for the resolve pass (16-byte lanes, w unused). 48 bytes.
+struct ColRec {
+    float4 a, b, c;
+};
+
+struct Target {
+    int32_t width, height;         // full framebuffer
+    int32_t row_begin, row_end;    // band owned by this context
+    int32_t tiles_x, tiles_y;      // tiles in the band
+};
+
+// device-side frame counters (one 32-bit word each)
+enum { CNT_PAIRS = 0, CNT_OVERFLOW = 1, CNT_BAD_INDEX = 2, CNT_WORDS = 8 };
+
+// Everything one frame needs, all device pointers.  colour/depth are band-local: element
+// (x, y) of the full image lives at [(y - row_begin) * width + x].
+struct DeviceFrame {
+    const swr_vertex* vertices;
+    const int64_t* indices;
+    int64_t vertex_count;
+    int64_t ntri;
+    GeomRec* geo;
+    ColRec* col;
+    uint32_t* tile_count;          // [tiles] (triangle,tile) pairs per tile
+    uint32_t* tile_start;          // [tiles+1] exclusive scan of tile_count
+    uint32_t* counters;            // [CNT_WORDS]
+    uint32_t* pair_tile;           // [capacity]
+    uint32_t* pair_slot;           // [capacity]
+    uint32_t* pair_prim;           // [capacity]
+    uint32_t* bins;                // [capacity] primitive ids grouped by tile
+    uint32_t capacity;
+    uint8_t* color;
+    float* depth;
+    Target tg;
+    float m[16];                   // column-major transform
+    uint32_t flags;                // SWR_FLAG_*
+};
+
+void launch_validate_indices(const int64_t* indices, int64_t count, int64_t vertex_count,
+                             uint32_t* counters, hipStream_t s);
+void launch_setup_bin(const DeviceFrame& f, hipStream_t s);
+void launch_scan(const DeviceFrame& f, hipStream_t s);
+void launch_scatter(const DeviceFrame& f, hipStream_t s);
+void launch_raster(const DeviceFrame& f, hipStream_t s);
+
+}  // namespace swr

@@ -1,0 +1,593 @@
+// swr_kernels.hip — gfx950 (CDNA4, wave64) kernels of the triangle hot path.
+//
+// Pipeline of one frame (all on one stream, no host round trip):
+//   k_setup_bin   1 lane / triangle : vertex_shader x3, /w, screen map, truncation, y-sort,
+//                                     T() = inverse 2x2, 64-B GeomRec (+48-B ColRec); bbox -> tiles;
+//                                     per overlapped tile a returning atomicAdd hands out the slot,
+//                                     (tile,slot,prim) appended to the pair list
+//   k_scan        1 workgroup       : exclusive scan of the per-tile counts
+//   k_scatter     1 lane / pair     : bins[tile_start[tile]+slot] = prim   (no atomics)
+//   k_raster      1 workgroup / tile: 64-bit visibility keys for the tile live in LDS; every
+//                                     lane walks the scanline spans of ITS OWN triangle and
+//                                     ds_min_u64's (depth|prim) keys into the tile; big triangles
+//                                     are walked by the whole wave (lane = pixel of a row chunk);
+//                                     resolve: key -> winning primitive -> barycentric colour ->
+//                                     fragment_shader -> one coalesced 16-B/lane framebuffer write
+//                                     (clear fused: HBM sees each pixel exactly once).
+//
+// Semantics restated from renderer/Renderer.swift (reference file:line cited inline):
+//   visibility without z-test = highest primitive index covering the pixel (painter's order of
+//   the serial loop :222); with z-test = smallest depth, ties -> lowest primitive index (strict
+//   '<' of :258).  Both are order-independent functions of the fragment set, so a commutative
+//   atomic min over (orderable depth << 32 | prim) [z] or (~prim) [no z] reproduces the serial
+//   loop bit for bit regardless of the order in which lanes, waves and bins deliver fragments.
+//
+// Float discipline: compiled with -ffp-contract=off; only + - * / in the order of the
+// reference; IEEE-correct division; the same expressions in setup, raster and resolve.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "swr_internal.h"
+#include "swr_shaders.hip.h"
+
+namespace swr {
+
+#define COORD_LIMIT 1073741824.0f  // 2^30, same skip rule as the oracle
+
+// ------------------------------------------------------------------------------------------
+// small helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t orderable_depth(float d) {
+    // monotone map float -> uint32 (valid for non-NaN): negative floats reversed, positive offset
+    uint32_t u = __float_as_uint(d);
+    return u ^ (uint32_t)(((int32_t)u >> 31) | 0x80000000);
+}
+__device__ __forceinline__ float depth_from_orderable(uint32_t k) {
+    uint32_t u = (k & 0x80000000u) ? (k ^ 0x80000000u) : ~k;
+    return __uint_as_float(u);
+}
+
+// trunc(n / d) for d > 0, |n| < 2^31, |n/d| < 2^20: float estimate + exact integer correction.
+__device__ __forceinline__ int tdiv_small(int n, int d, float rcp_d) {
+    int an = n < 0 ? -n : n;
+    int q = (int)((float)an * rcp_d);
+    int r = an - q * d;
+    if (r < 0) { q -= 1; r += d; }
+    if (r >= d) { q += 1; }
+    return n < 0 ? -q : q;
+}
+
+// Sorted integer vertices + chain data of one triangle, as the span walker needs them.
+struct Chains {
+    int s0x, s0y, s1x, s1y, s2x, s2y;
+    float r01, r12, r02;   // reciprocals of the three dy's (fast path only)
+    bool small;
+};
+
+// Renderer.interpolate (:467-494) for both chains of row y, then the swap of :278-280.
+// Returns the inclusive span [lo, hi].
+__device__ __forceinline__ void row_span(const Chains& c, int y, int& lo, int& hi) {
+    // left chain: 3 points [S0,S1,S2] (:469-475 base selection)
+    const bool last = y >= c.s2y;
+    const bool seg1 = y >= c.s1y;
+    int x0 = last ? c.s2x : (seg1 ? c.s1x : c.s0x);
+    int y0 = seg1 ? c.s1y : c.s0y;
+    int dx = last ? 0 : (seg1 ? c.s2x - c.s1x : c.s1x - c.s0x);
+    int dy = last ? 1 : (seg1 ? c.s2y - c.s1y : c.s1y - c.s0y);
+    float rd = seg1 ? c.r12 : c.r01;
+    // right chain: 2 points [S0,S2]; dy == 0 -> S0.x (:486-488)
+    const int dyr = c.s2y - c.s0y;
+    const int dxr = dyr ? c.s2x - c.s0x : 0;
+    int L, R;
+    if (c.small) {
+        L = x0 + tdiv_small(dx * (y - y0), dy, last ? 1.0f : rd);
+        R = c.s0x + tdiv_small(dxr * (y - c.s0y), dyr ? dyr : 1, dyr ? c.r02 : 1.0f);
+    } else {
+        L = x0 + (int)(((int64_t)dx * (int64_t)(y - y0)) / (int64_t)dy);
+        R = c.s0x + (int)(((int64_t)dxr * (int64_t)(y - c.s0y)) / (int64_t)(dyr ? dyr : 1));
+    }
+    lo = L < R ? L : R;
+    hi = L < R ? R : L;
+}
+
+// ------------------------------------------------------------------------------------------
+// index validation (Swift would trap on an out-of-range index, Renderer.swift:226)
+// ------------------------------------------------------------------------------------------
+__global__ void k_validate_indices(const int64_t* __restrict__ idx, int64_t n, int64_t nv,
+                                   uint32_t* counters) {
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    bool bad = false;
+    for (; i < n; i += stride) {
+        int64_t v = idx[i];
+        bad |= (v < 0) | (v >= nv);
+    }
+    if (bad) atomicOr(&counters[CNT_BAD_INDEX], 1u);
+}
+
+// ------------------------------------------------------------------------------------------
+// k_setup_bin
+// ------------------------------------------------------------------------------------------
+struct SetupArgs {
+    const swr_vertex* vertices;
+    const int64_t* indices;
+    int64_t ntri;
+    GeomRec* geo;
+    ColRec* col;            // may be null (depth-only)
+    uint32_t* tile_count;
+    uint32_t* counters;
+    uint32_t* pair_tile;
+    uint32_t* pair_slot;
+    uint32_t* pair_prim;
+    uint32_t capacity;
+    Target tg;
+    float4x4 m;
+};
+
+__global__ __launch_bounds__(256) void k_setup_bin(SetupArgs a) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.ntri) return;
+
+    // :223-227 — three vertex references of primitive p, in index order
+    const int64_t i0 = a.indices[3 * p + 0];
+    const int64_t i1 = a.indices[3 * p + 1];
+    const int64_t i2 = a.indices[3 * p + 2];
+    const float4* vp = reinterpret_cast<const float4*>(a.vertices);
+    const float4 xa = vp[2 * i0], ca = vp[2 * i0 + 1];
+    const float4 xb = vp[2 * i1], cb = vp[2 * i1 + 1];
+    const float4 xc = vp[2 * i2], cc = vp[2 * i2 + 1];
+
+    const float fw = (float)a.tg.width, fh = (float)a.tg.height;
+    float sx[3], sy[3], sz[3];
+    {
+        const float4 xs[3] = {xa, xb, xc};
+        const float4 cs[3] = {ca, cb, cc};
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            // Vertex.apply(transform:) (:159-163) through the vertex_shader hook
+            VertexOut vo = vertex_shader(make_float3(xs[k].x, xs[k].y, xs[k].z),
+                                         make_float3(cs[k].x, cs[k].y, cs[k].z), a.m);
+            const float nx = vo.pos.x / vo.pos.w;
+            const float ny = vo.pos.y / vo.pos.w;
+            const float nz = vo.pos.z / vo.pos.w;
+            // convertedToScreen (:165-171)
+            const float u = nx * 0.5f + 0.5f;
+            const float v = ny * -0.5f + 0.5f;
+            sx[k] = u * fw;
+            sy[k] = v * fh;
+            sz[k] = nz;
+        }
+    }
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 3; k++)
+        ok = ok && (fabsf(sx[k]) < COORD_LIMIT) && (fabsf(sy[k]) < COORD_LIMIT);
+
+    GeomRec g;
+    g.prim = (uint32_t)p;
+    g.flags = 0;
+    g.pad = 0.0f;
+    g.za = sz[0]; g.zb = sz[1]; g.zc = sz[2];
+    int ix[3] = {0, 0, 0}, iy[3] = {0, 0, 0};
+    if (ok) {
+#pragma unroll
+        for (int k = 0; k < 3; k++) { ix[k] = (int)sx[k]; iy[k] = (int)sy[k]; }  // :251 truncation
+    }
+    // T() (:95-100): columns (af - cf), (bf - cf); inverse = adjugate / determinant
+    const float cfx = (float)ix[2] + 0.5f, cfy = (float)iy[2] + 0.5f;
+    const float m00 = ((float)ix[0] + 0.5f) - cfx, m10 = ((float)iy[0] + 0.5f) - cfy;
+    const float m01 = ((float)ix[1] + 0.5f) - cfx, m11 = ((float)iy[1] + 0.5f) - cfy;
+    const float det = m00 * m11 - m01 * m10;
+    ok = ok && (det != 0.0f) && (fabsf(det) < INFINITY);
+    g.t00 = m11 / det; g.t01 = -m01 / det; g.t10 = -m10 / det; g.t11 = m00 / det;
+    g.ax = ix[0]; g.ay = iy[0]; g.bx = ix[1]; g.by = iy[1]; g.cx = ix[2]; g.cy = iy[2];
+
+    // :271 stable 3-element insertion sort on FLOAT y
+    int o0 = 0, o1 = 1, o2 = 2;
+    if (sy[o1] < sy[o0]) { int t = o0; o0 = o1; o1 = t; }
+    if (sy[o2] < sy[o1]) {
+        int t = o1; o1 = o2; o2 = t;
+        if (sy[o1] < sy[o0]) { t = o0; o0 = o1; o1 = t; }
+    }
+    const int s0x = ix[o0], s0y = iy[o0], s1x = ix[o1], s1y = iy[o1], s2x = ix[o2], s2y = iy[o2];
+    int minx = min(ix[0], min(ix[1], ix[2])), maxx = max(ix[0], max(ix[1], ix[2]));
+    {
+        // 32-bit span arithmetic is exact when every |dx| < 2^15 and every dy < 2^16
+        const int64_t w = (int64_t)maxx - (int64_t)minx;
+        const int64_t h = (int64_t)s2y - (int64_t)s0y;
+        const bool small = (w < 32768) && (h < 65536);
+        g.flags = (ok ? GEOM_VALID : 0u) | (small ? GEOM_SMALL : 0u) |
+                  ((uint32_t)o0 << GEOM_ORD_SHIFT) | ((uint32_t)o1 << (GEOM_ORD_SHIFT + 2)) |
+                  ((uint32_t)o2 << (GEOM_ORD_SHIFT + 4));
+    }
+    (void)s0x; (void)s1x; (void)s1y; (void)s2x;
+
+    // record stores: 4 x 16 B per lane
+    {
+        int4* gp = reinterpret_cast<int4*>(a.geo + p);
+        gp[0] = make_int4(g.ax, g.ay, g.bx, g.by);
+        gp[1] = make_int4(g.cx, g.cy, (int)g.flags, (int)g.prim);
+        reinterpret_cast<float4*>(gp)[2] = make_float4(g.t00, g.t01, g.t10, g.t11);
+        reinterpret_cast<float4*>(gp)[3] = make_float4(g.za, g.zb, g.zc, 0.0f);
+        if (a.col) {
+            float4* cp = reinterpret_cast<float4*>(a.col + p);
+            cp[0] = ca; cp[1] = cb; cp[2] = cc;
+        }
+    }
+    if (!ok) return;
+
+    // bbox ∩ band -> tiles.  Every covered pixel lies in [minx,maxx] x [S0.y,S2.y] (spans are
+    // integer interpolants between vertex x's, :467-494).
+    int x0 = max(minx, 0), x1 = min(maxx, a.tg.width - 1);
+    int y0 = max(s0y, a.tg.row_begin), y1 = min(s2y, a.tg.row_end - 1);
+    if (x0 > x1 || y0 > y1) return;
+    const int tx0 = x0 / TILE_W, tx1 = x1 / TILE_W;
+    const int ty0 = (y0 - a.tg.row_begin) / TILE_H, ty1 = (y1 - a.tg.row_begin) / TILE_H;
+    for (int ty = ty0; ty <= ty1; ty++) {
+        for (int tx = tx0; tx <= tx1; tx++) {
+            const uint32_t tile = (uint32_t)(ty * a.tg.tiles_x + tx);
+            const uint32_t slot = atomicAdd(&a.tile_count[tile], 1u);
+            const uint32_t e = atomicAdd(&a.counters[CNT_PAIRS], 1u);   // wave-aggregated by hipcc
+            if (e < a.capacity) {
+                a.pair_tile[e] = tile;
+                a.pair_slot[e] = slot;
+                a.pair_prim[e] = (uint32_t)p;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_scan: exclusive scan of tile_count -> tile_start[0..tiles], one workgroup
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ count,
+                                               uint32_t* __restrict__ start, int n,
+                                               uint32_t* counters, uint32_t capacity) {
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    const int per = (n + 1023) / 1024;
+    const int b = t * per, e = min(b + per, n);
+    uint32_t s = 0;
+    for (int i = b; i < e; i++) s += count[i];
+    part[t] = s;
+    __syncthreads();
+    // Hillis-Steele inclusive scan over 1024 partials
+    for (int off = 1; off < 1024; off <<= 1) {
+        uint32_t v = (t >= off) ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - s;
+    for (int i = b; i < e; i++) { start[i] = run; run += count[i]; }
+    if (t == 1023) {
+        start[n] = part[1023];
+        if (part[1023] > capacity) counters[CNT_OVERFLOW] = 1u;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_scatter
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ pair_tile,
+                                                 const uint32_t* __restrict__ pair_slot,
+                                                 const uint32_t* __restrict__ pair_prim,
+                                                 const uint32_t* __restrict__ tile_start,
+                                                 const uint32_t* __restrict__ counters,
+                                                 uint32_t* __restrict__ bins, uint32_t capacity) {
+    const uint32_t total = counters[CNT_PAIRS];
+    if (total > capacity) return;   // overflow: the host grows the buffers and redraws
+    const uint32_t stride = gridDim.x * 256u;
+    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total; e += stride)
+        bins[tile_start[pair_tile[e]] + pair_slot[e]] = pair_prim[e];
+}
+
+// ------------------------------------------------------------------------------------------
+// k_raster
+// ------------------------------------------------------------------------------------------
+struct RasterArgs {
+    const GeomRec* geo;
+    const ColRec* col;
+    const uint32_t* tile_start;
+    const uint32_t* bins;
+    const uint32_t* counters;
+    uint32_t capacity;
+    uint8_t* color;     // band-local BGRA8
+    float* depth;       // band-local f32
+    Target tg;
+};
+
+constexpr unsigned long long KEY_EMPTY = ~0ull;
+constexpr int BIG_AREA = 384;   // clipped bbox area above which a triangle is walked by the whole wave
+
+// Per-lane triangle state for the span walk.
+struct TriState {
+    Chains ch;
+    float cfx, cfy;            // float(C) + 0.5 (:89)
+    float t00, t01, t10, t11;
+    float za, zb, zc;
+    uint32_t prim;
+};
+
+template <bool ZTEST>
+__device__ __forceinline__ void fragment(unsigned long long* keys, const TriState& t, int x, int lidx,
+                                         float r0, float r1) {
+    // setPixel (:245-269): weights at the pixel centre (x+.5, y+.5) relative to cf
+    unsigned long long key;
+    if (ZTEST) {
+        const float px = (float)x + 0.5f;
+        const float dx = px - t.cfx;
+        const float w0 = t.t00 * dx + r0;          // r0 = t01 * dy
+        const float w1 = t.t10 * dx + r1;          // r1 = t11 * dy
+        const float w2 = 1.0f - w0 - w1;           // :92
+        float d = t.za * w0 + t.zb * w1 + t.zc * w2;   // :257
+        if (!(d < INFINITY)) return;               // can never pass 'depth < buffer' (:258); NaN too
+        d = d + 0.0f;                              // -0 -> +0 for ordering only (== under '<')
+        key = ((unsigned long long)orderable_depth(d) << 32) | (unsigned long long)t.prim;
+    } else {
+        key = (unsigned long long)(0xFFFFFFFFu - t.prim);   // painter's order: highest prim wins
+    }
+    atomicMin(&keys[lidx], key);
+}
+
+__device__ __forceinline__ void load_tri(const GeomRec* __restrict__ geo, uint32_t prim, TriState& t,
+                                         int& minx, int& maxx) {
+    const int4* gp = reinterpret_cast<const int4*>(geo + prim);
+    const int4 q0 = gp[0];
+    const int4 q1 = gp[1];
+    const float4 q2 = reinterpret_cast<const float4*>(gp)[2];
+    const float4 q3 = reinterpret_cast<const float4*>(gp)[3];
+    const int vx[3] = {q0.x, q0.z, q1.x};
+    const int vy[3] = {q0.y, q0.w, q1.y};
+    const uint32_t fl = (uint32_t)q1.z;
+    const int o0 = (fl >> GEOM_ORD_SHIFT) & 3, o1 = (fl >> (GEOM_ORD_SHIFT + 2)) & 3,
+              o2 = (fl >> (GEOM_ORD_SHIFT + 4)) & 3;
+    // select without dynamic indexing (keeps the arrays in registers)
+    auto pick = [](int o, int a, int b, int c) { return o == 0 ? a : (o == 1 ? b : c); };
+    t.ch.s0x = pick(o0, vx[0], vx[1], vx[2]); t.ch.s0y = pick(o0, vy[0], vy[1], vy[2]);
+    t.ch.s1x = pick(o1, vx[0], vx[1], vx[2]); t.ch.s1y = pick(o1, vy[0], vy[1], vy[2]);
+    t.ch.s2x = pick(o2, vx[0], vx[1], vx[2]); t.ch.s2y = pick(o2, vy[0], vy[1], vy[2]);
+    t.ch.small = (fl & GEOM_SMALL) != 0;
+    t.ch.r01 = __builtin_amdgcn_rcpf((float)(t.ch.s1y - t.ch.s0y));
+    t.ch.r12 = __builtin_amdgcn_rcpf((float)(t.ch.s2y - t.ch.s1y));
+    t.ch.r02 = __builtin_amdgcn_rcpf((float)(t.ch.s2y - t.ch.s0y));
+    t.cfx = (float)q1.x + 0.5f;
+    t.cfy = (float)q1.y + 0.5f;
+    t.t00 = q2.x; t.t01 = q2.y; t.t10 = q2.z; t.t11 = q2.w;
+    t.za = q3.x; t.zb = q3.y; t.zc = q3.z;
+    t.prim = prim;
+    minx = min(vx[0], min(vx[1], vx[2]));
+    maxx = max(vx[0], max(vx[1], vx[2]));
+}
+
+__device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
+__device__ __forceinline__ float bcast_f(float v, int src) {
+    return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
+}
+
+template <bool ZTEST>
+__global__ __launch_bounds__(RASTER_THREADS) void k_raster(RasterArgs a) {
+    __shared__ unsigned long long keys[TILE_W * TILE_H];
+
+    const int tile = blockIdx.x;
+    const int tx = tile % a.tg.tiles_x, ty = tile / a.tg.tiles_x;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    // tile rectangle in full-image coordinates (inclusive)
+    const int X0 = tx * TILE_W, Y0 = a.tg.row_begin + ty * TILE_H;
+    const int X1 = min(X0 + TILE_W, a.tg.width) - 1;
+    const int Y1 = min(Y0 + TILE_H, a.tg.row_end) - 1;
+
+    // clear fused into the LDS init (Renderer.clear :205-206, :232-236)
+    for (int i = tid; i < TILE_W * TILE_H; i += RASTER_THREADS) keys[i] = KEY_EMPTY;
+    __syncthreads();
+
+    const bool overflow = a.counters[CNT_PAIRS] > a.capacity;
+    const uint32_t b0 = overflow ? 0u : a.tile_start[tile];
+    const uint32_t b1 = overflow ? 0u : a.tile_start[tile + 1];
+
+    for (uint32_t base = b0; base < b1; base += RASTER_THREADS) {
+        const uint32_t e = base + tid;
+        const bool have = e < b1;
+        TriState t;
+        int ya = 1, yb = 0, bxa = 0, bxb = -1;
+        bool big = false;
+        if (have) {
+            int minx, maxx;
+            load_tri(a.geo, a.bins[e], t, minx, maxx);
+            ya = max(t.ch.s0y, Y0);
+            yb = min(t.ch.s2y, Y1);
+            bxa = max(minx, X0);
+            bxb = min(maxx, X1);
+            big = (yb - ya + 1) * (bxb - bxa + 1) > BIG_AREA;
+        }
+
+        // ---- phase 1: every lane walks the spans of its own (small) triangle ----------------
+        if (have && !big) {
+            for (int y = ya; y <= yb; y++) {
+                int lo, hi;
+                row_span(t.ch, y, lo, hi);
+                lo = max(lo, X0);
+                hi = min(hi, X1);
+                const float dy = ((float)y + 0.5f) - t.cfy;
+                const float r0 = t.t01 * dy, r1 = t.t11 * dy;
+                const int rowbase = (y - Y0) * TILE_W - X0;
+                for (int x = lo; x <= hi; x++) fragment<ZTEST>(keys, t, x, rowbase + x, r0, r1);
+            }
+        }
+
+        // ---- phase 2: big triangles, one at a time, walked by the whole wave ----------------
+        unsigned long long bigmask = __ballot(have && big);
+        while (bigmask) {
+            const int src = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)bigmask) - 1);
+            bigmask &= bigmask - 1;
+            TriState u;
+            u.ch.s0x = bcast_i(t.ch.s0x, src); u.ch.s0y = bcast_i(t.ch.s0y, src);
+            u.ch.s1x = bcast_i(t.ch.s1x, src); u.ch.s1y = bcast_i(t.ch.s1y, src);
+            u.ch.s2x = bcast_i(t.ch.s2x, src); u.ch.s2y = bcast_i(t.ch.s2y, src);
+            u.ch.r01 = bcast_f(t.ch.r01, src); u.ch.r12 = bcast_f(t.ch.r12, src);
+            u.ch.r02 = bcast_f(t.ch.r02, src);
+            u.ch.small = bcast_i(t.ch.small ? 1 : 0, src) != 0;
+            u.cfx = bcast_f(t.cfx, src); u.cfy = bcast_f(t.cfy, src);
+            u.t00 = bcast_f(t.t00, src); u.t01 = bcast_f(t.t01, src);
+            u.t10 = bcast_f(t.t10, src); u.t11 = bcast_f(t.t11, src);
+            u.za = bcast_f(t.za, src); u.zb = bcast_f(t.zb, src); u.zc = bcast_f(t.zc, src);
+            u.prim = (uint32_t)bcast_i((int)t.prim, src);
+            const int uya = bcast_i(ya, src), uyb = bcast_i(yb, src);
+
+            for (int yc = uya; yc <= uyb; yc += 64) {
+                // lane = row: each lane computes the span of one row of this 64-row chunk
+                const int yrow = yc + lane;
+                int lo = 0, hi = -1;
+                if (yrow <= uyb) {
+                    row_span(u.ch, yrow, lo, hi);
+                    lo = max(lo, X0);
+                    hi = min(hi, X1);
+                }
+                // chunk shape from the widest span: 16x4, 32x2 or 64x1 pixels per wave step
+                int wmax = hi - lo + 1;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off));
+                const int lw = wmax <= 16 ? 4 : (wmax <= 32 ? 5 : 6);
+                const int cw = 1 << lw, rows_per = 64 >> lw;
+                const int nrows = min(64, uyb - yc + 1);
+                for (int r0i = 0; r0i < nrows; r0i += rows_per) {
+                    const int r = r0i + (lane >> lw);
+                    const int rlo = __shfl(lo, r & 63), rhi = __shfl(hi, r & 63);
+                    const int y = yc + r;
+                    const bool rowok = r < nrows;
+                    const float dy = ((float)y + 0.5f) - u.cfy;
+                    const float q0 = u.t01 * dy, q1 = u.t11 * dy;
+                    const int rowbase = (y - Y0) * TILE_W - X0;
+                    if (rowok)
+                        for (int x = rlo + (lane & (cw - 1)); x <= rhi; x += cw)
+                            fragment<ZTEST>(keys, u, x, rowbase + x, q0, q1);
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---- resolve: key -> pixel, one coalesced write per pixel --------------------------------
+    const bool want_color = a.color != nullptr;
+    const int W = a.tg.width;
+    const bool vec_ok = (W & 3) == 0;
+    for (int i = tid; i < TILE_W * TILE_H / 4; i += RASTER_THREADS) {
+        const int ly = (i * 4) / TILE_W, lx = (i * 4) % TILE_W;
+        const int y = Y0 + ly, x = X0 + lx;
+        if (y > Y1 || x > X1) continue;
+        uint32_t cpix[4];
+        float dpix[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long key = keys[ly * TILE_W + lx + k];
+            uint32_t c = 0u;               // Pixel(0,0,0,0) (:205)
+            float d = INFINITY;            // (:206)
+            if (key != KEY_EMPTY && x + k <= X1) {
+                const uint32_t prim = ZTEST ? (uint32_t)key : 0xFFFFFFFFu - (uint32_t)key;
+                const uint32_t hi = (uint32_t)(key >> 32);
+                bool need_rec = want_color;
+                if (ZTEST) {
+                    d = depth_from_orderable(hi);
+                    need_rec = need_rec || (d == 0.0f);   // sign of zero comes from the winner
+                }
+                if (need_rec) {
+                    const int4* gp = reinterpret_cast<const int4*>(a.geo + prim);
+                    const int4 q1 = gp[1];
+                    const float4 q2 = reinterpret_cast<const float4*>(gp)[2];
+                    const float4 q3 = reinterpret_cast<const float4*>(gp)[3];
+                    const float cfx = (float)q1.x + 0.5f, cfy = (float)q1.y + 0.5f;
+                    const float dx = ((float)(x + k) + 0.5f) - cfx;
+                    const float dy = ((float)y + 0.5f) - cfy;
+                    const float w0 = q2.x * dx + q2.y * dy;
+                    const float w1 = q2.z * dx + q2.w * dy;
+                    const float w2 = 1.0f - w0 - w1;
+                    if (ZTEST) d = q3.x * w0 + q3.y * w1 + q3.z * w2;
+                    if (want_color) {
+                        const float4* cp = reinterpret_cast<const float4*>(a.col + prim);
+                        const float4 ca = cp[0], cb = cp[1], cc = cp[2];
+                        VertexOut vin;
+                        vin.pos = make_float4((float)(x + k) + 0.5f, (float)y + 0.5f, d, 1.0f);
+                        vin.color = make_float3(ca.x * w0 + cb.x * w1 + cc.x * w2,     // :266
+                                                ca.y * w0 + cb.y * w1 + cc.y * w2,
+                                                ca.z * w0 + cb.z * w1 + cc.z * w2);
+                        const float4 f = fragment_shader(vin);
+                        // Pixel(float3:) -> .floats(b: z, g: y, r: x, a: 1) (:116-128)
+                        const uint32_t qb = (uint32_t)(fminf(fmaxf(f.z, 0.0f), 1.0f) * 255.0f);
+                        const uint32_t qg = (uint32_t)(fminf(fmaxf(f.y, 0.0f), 1.0f) * 255.0f);
+                        const uint32_t qr = (uint32_t)(fminf(fmaxf(f.x, 0.0f), 1.0f) * 255.0f);
+                        const uint32_t qa = (uint32_t)(fminf(fmaxf(f.w, 0.0f), 1.0f) * 255.0f);
+                        c = qb | (qg << 8) | (qr << 16) | (qa << 24);
+                    }
+                }
+            }
+            cpix[k] = c;
+            dpix[k] = d;
+        }
+        const size_t at = (size_t)(y - a.tg.row_begin) * (size_t)W + (size_t)x;   // App.swift:351-360
+        if (vec_ok && x + 3 <= X1) {
+            if (want_color)
+                *reinterpret_cast<uint4*>(a.color + at * 4) = make_uint4(cpix[0], cpix[1], cpix[2], cpix[3]);
+            *reinterpret_cast<float4*>(a.depth + at) = make_float4(dpix[0], dpix[1], dpix[2], dpix[3]);
+        } else {
+            for (int k = 0; k < 4 && x + k <= X1; k++) {
+                if (want_color) reinterpret_cast<uint32_t*>(a.color)[at + k] = cpix[k];
+                a.depth[at + k] = dpix[k];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// launch wrappers
+// ------------------------------------------------------------------------------------------
+void launch_validate_indices(const int64_t* indices, int64_t count, int64_t vertex_count,
+                             uint32_t* counters, hipStream_t s) {
+    if (count <= 0) return;
+    int64_t blocks = (count + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_validate_indices, dim3((unsigned)blocks), dim3(256), 0, s, indices, count,
+                       vertex_count, counters);
+}
+
+void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
+    if (f.ntri <= 0) return;
+    SetupArgs a;
+    a.vertices = f.vertices; a.indices = f.indices; a.ntri = f.ntri;
+    a.geo = f.geo; a.col = (f.flags & SWR_FLAG_NO_COLOR) ? nullptr : f.col;
+    a.tile_count = f.tile_count; a.counters = f.counters;
+    a.pair_tile = f.pair_tile; a.pair_slot = f.pair_slot; a.pair_prim = f.pair_prim;
+    a.capacity = f.capacity; a.tg = f.tg;
+    for (int c = 0; c < 4; c++)
+        a.m.columns[c] = make_float4(f.m[4 * c + 0], f.m[4 * c + 1], f.m[4 * c + 2], f.m[4 * c + 3]);
+    const unsigned blocks = (unsigned)((f.ntri + 255) / 256);
+    hipLaunchKernelGGL(k_setup_bin, dim3(blocks), dim3(256), 0, s, a);
+}
+
+void launch_scan(const DeviceFrame& f, hipStream_t s) {
+    const int n = f.tg.tiles_x * f.tg.tiles_y;
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, f.tile_count, f.tile_start, n, f.counters,
+                       f.capacity);
+}
+
+void launch_scatter(const DeviceFrame& f, hipStream_t s) {
+    if (f.ntri <= 0) return;
+    hipLaunchKernelGGL(k_scatter, dim3(2048), dim3(256), 0, s, f.pair_tile, f.pair_slot, f.pair_prim,
+                       f.tile_start, f.counters, f.bins, f.capacity);
+}
+
+void launch_raster(const DeviceFrame& f, hipStream_t s) {
+    RasterArgs a;
+    a.geo = f.geo; a.col = f.col; a.tile_start = f.tile_start; a.bins = f.bins;
+    a.counters = f.counters; a.capacity = f.capacity;
+    a.color = (f.flags & SWR_FLAG_NO_COLOR) ? nullptr : f.color;
+    a.depth = f.depth; a.tg = f.tg;
+    const unsigned tiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
+    if (tiles == 0) return;
+    if (f.flags & SWR_FLAG_DEPTH_TEST)
+        hipLaunchKernelGGL(k_raster<true>, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+    else
+        hipLaunchKernelGGL(k_raster<false>, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+}
+
+}  // namespace swr

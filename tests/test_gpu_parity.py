@@ -1,0 +1,306 @@
+"""Parity tests proper: the HIP path, called through the C-ABI (include/swr.h), against the CPU
+oracle on the same seeded inputs.  Bar: bit-exact colour bytes and depth bits (the north star
+allows 1 LSB per channel for the unpinned Apple-simd gap between the oracle and the Swift
+original; between OUR two implementations of the same restatement nothing may differ).
+
+Covers the cases the reference's code paths imply: flat-top / flat-bottom,
+left>right swap, shared edges, off-screen pixels (scissor), painter's order vs z-order,
+equal-depth ties, truncation of coordinates and of 8-bit colour, degenerate / non-finite input,
+empty input, ragged framebuffer sizes, bands, and the BASELINE configs at full size.
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DT, NC = 1, 2
+
+
+def assert_same(got_c, got_d, ref_c, ref_d, what=""):
+    if ref_c is not None:
+        diff = np.nonzero((got_c != ref_c).any(axis=-1))
+        assert diff[0].size == 0, (
+            f"{what}: {diff[0].size} colour pixels differ; first (y,x)=({diff[0][0]},{diff[1][0]}) "
+            f"got {got_c[diff[0][0], diff[1][0]]} want {ref_c[diff[0][0], diff[1][0]]}")
+    gb, rb = got_d.view(np.uint32), ref_d.view(np.uint32)
+    diff = np.nonzero(gb != rb)
+    assert diff[0].size == 0, (
+        f"{what}: {diff[0].size} depth values differ; first (y,x)=({diff[0][0]},{diff[1][0]}) "
+        f"got {got_d[diff[0][0], diff[1][0]]!r} want {ref_d[diff[0][0], diff[1][0]]!r}")
+
+
+def check(ctx, oracle, scene, flags=None, what=None):
+    flags = scene.flags if flags is None else flags
+    rc_c, rc_d, st, rc = oracle.render(scene.vertices, scene.indices, scene.transform,
+                                       scene.width, scene.height, flags | oracle.TINV_PER_TRIANGLE)
+    assert rc == 0
+    c, d = ctx.render(scene.vertices, scene.indices, scene.transform, scene.width, scene.height, flags)
+    assert_same(c, d, rc_c, rc_d, what or f"{scene.name} flags={flags}")
+    return st
+
+
+# ---------------------------------------------------------------------------------------------
+def test_cfg1_kat(gpu_ctx, swr):
+    """SURVEY.md §C.1 known answer, straight from the GPU (no oracle in the loop)."""
+    s = swr.scenes.cfg1_triangle()
+    c, d = gpu_ctx.render(s.vertices, s.indices, s.transform, 256, 256, 0)
+    cov = c[..., 3] == 255
+    assert cov.sum() == 8193
+    assert (c[cov] == np.array([63, 127, 255, 255], dtype=np.uint8)).all()
+    assert (c[~cov] == 0).all()
+    assert np.isposinf(d).all()
+    for y, lo, hi in ((64, 128, 128), (65, 128, 128), (128, 96, 160), (191, 65, 191), (192, 64, 64)):
+        xs = np.nonzero(cov[y])[0]
+        assert (xs.min(), xs.max()) == (lo, hi)
+
+
+def test_cfg1_gouraud_kat(gpu_ctx, swr):
+    s = swr.scenes.cfg1_triangle(gouraud=True)
+    c, _ = gpu_ctx.render(s.vertices, s.indices, s.transform, 256, 256, 0)
+    assert tuple(c[100, 128]) == (35, 35, 183, 255)
+    assert tuple(c[150, 100]) == (141, 29, 83, 255)
+    assert tuple(c[190, 160]) == (61, 189, 3, 255)
+
+
+@pytest.mark.parametrize("flags", [0, DT, DT | NC])
+@pytest.mark.parametrize("ntri,w,h,r,seed", [
+    (1, 64, 64, 0.5, 1), (7, 64, 32, 0.6, 2), (300, 256, 256, 0.15, 3), (2000, 640, 360, 0.05, 4),
+    (5000, 1000, 700, 0.02, 5), (400, 255, 129, 0.3, 6), (64, 37, 61, 0.9, 7), (20000, 512, 512, 0.01, 8),
+])
+def test_random_soup(gpu_ctx, oracle, swr, ntri, w, h, r, seed, flags):
+    s = swr.scenes.random_soup(ntri, w, h, seed, r_ndc=r, flags=flags, margin=1.2)
+    st = check(gpu_ctx, oracle, s)
+    assert st.triangles_drawn > 0
+
+
+@pytest.mark.parametrize("flags", [0, DT])
+def test_shared_vertices_indexed(gpu_ctx, oracle, swr, flags):
+    s = swr.scenes.random_soup(3000, 800, 600, 11, r_ndc=0.4, flags=flags, margin=1.0, shared=True)
+    check(gpu_ctx, oracle, s)
+
+
+@pytest.mark.parametrize("flags", [0, DT, DT | NC])
+def test_big_triangles_cooperative_path(gpu_ctx, oracle, swr, flags):
+    """Triangles far larger than a tile: the whole-wave walk (phase 2 of k_raster)."""
+    s = swr.scenes.random_soup(40, 1920, 1080, 21, r_ndc=1.3, flags=flags, margin=0.8)
+    check(gpu_ctx, oracle, s)
+
+
+@pytest.mark.parametrize("flags", [0, DT])
+def test_mixed_sizes(gpu_ctx, oracle, swr, flags):
+    a = swr.scenes.random_soup(30, 1280, 720, 31, r_ndc=1.0, flags=flags, margin=0.9)
+    b = swr.scenes.random_soup(6000, 1280, 720, 32, r_ndc=0.03, flags=flags, margin=1.1)
+    nv = a.vertices.shape[0]
+    # interleave big and small primitives so painter's order matters
+    tri_a = a.indices.reshape(-1, 3)
+    tri_b = b.indices.reshape(-1, 3) + nv
+    order = np.argsort(swr.scenes.splitmix64(99, tri_a.shape[0] + tri_b.shape[0]))
+    idx = np.concatenate([tri_a, tri_b])[order].reshape(-1)
+    s = swr.scenes.Scene("mixed", 1280, 720, np.concatenate([a.vertices, b.vertices]), idx,
+                         swr.scenes.identity(), flags)
+    check(gpu_ctx, oracle, s)
+
+
+def test_huge_coordinates_slow_path(gpu_ctx, oracle, swr):
+    """Vertices far off-screen (|x| up to ~1e5 px): 64-bit span arithmetic path."""
+    xyz = np.array([[-200.0, -150.0, 0.2], [180.0, 0.3, 0.9], [0.1, 160.0, 0.5],
+                    [-0.9, -0.9, 0.1], [300.0, -0.8, 0.4], [-0.8, 250.0, 0.7],
+                    [-500.0, 0.0, 0.3], [500.0, 0.01, 0.3], [0.0, 0.9, 0.3]], dtype=np.float32)
+    rgb = np.array([[1, 0, 0], [0, 1, 0], [0, 0, 1]] * 3, dtype=np.float32)
+    for flags in (0, DT):
+        s = swr.scenes.Scene("huge", 640, 480, swr.scenes.pack_vertices(xyz, rgb),
+                             np.arange(9, dtype=np.int64), swr.scenes.identity(), flags)
+        check(gpu_ctx, oracle, s)
+
+
+def test_depth_ties_first_drawn_wins(gpu_ctx, oracle, swr):
+    """Coplanar duplicates with different colours: strict '<' keeps the first (Renderer.swift:258)."""
+    xyz = np.array([[0.0, 0.8, 0.5], [0.8, -0.8, 0.5], [-0.8, -0.8, 0.5]] * 3, dtype=np.float32)
+    rgb = np.array([[1, 0, 0]] * 3 + [[0, 1, 0]] * 3 + [[0, 0, 1]] * 3, dtype=np.float32)
+    s = swr.scenes.Scene("ties", 200, 200, swr.scenes.pack_vertices(xyz, rgb),
+                         np.arange(9, dtype=np.int64), swr.scenes.identity(), DT)
+    check(gpu_ctx, oracle, s)
+    c, _ = gpu_ctx.render(s.vertices, s.indices, s.transform, 200, 200, DT)
+    assert tuple(c[100, 100]) == (0, 0, 255, 255)      # red (first) in BGRA
+    c, _ = gpu_ctx.render(s.vertices, s.indices, s.transform, 200, 200, 0)
+    assert tuple(c[100, 100]) == (255, 0, 0, 255)      # blue (last) without z-test
+
+
+def test_signed_zero_depth(gpu_ctx, oracle, swr):
+    """z = -0.0 and +0.0 compare equal under '<': the first drawn keeps its sign bit."""
+    for zs in ((-0.0, 0.0), (0.0, -0.0)):
+        xyz = np.array([[0.0, 0.8, zs[0]], [0.8, -0.8, zs[0]], [-0.8, -0.8, zs[0]],
+                        [0.0, 0.7, zs[1]], [0.9, -0.8, zs[1]], [-0.9, -0.9, zs[1]]], dtype=np.float32)
+        rgb = np.ones((6, 3), dtype=np.float32)
+        for flags in (DT, DT | NC):
+            s = swr.scenes.Scene("zero", 96, 96, swr.scenes.pack_vertices(xyz, rgb),
+                                 np.arange(6, dtype=np.int64), swr.scenes.identity(), flags)
+            check(gpu_ctx, oracle, s)
+
+
+def test_negative_and_out_of_range_depth(gpu_ctx, oracle, swr):
+    s = swr.scenes.random_soup(500, 300, 200, 41, r_ndc=0.3, flags=DT)
+    s.vertices[:, 2] = s.vertices[:, 2] * 6.0 - 3.0      # z in [-3, 3): negative and > 1
+    check(gpu_ctx, oracle, s)
+
+
+def test_degenerate_and_nonfinite_triangles_skipped(gpu_ctx, oracle, swr):
+    s = swr.scenes.random_soup(200, 256, 256, 51, r_ndc=0.2, flags=DT)
+    v = s.vertices
+    v[0:3, 0:2] = v[0, 0:2]                  # zero-area
+    v[3:6, 1] = 0.25                         # collinear (same y)
+    v[9, 0] = np.nan
+    v[12, 1] = np.inf
+    v[15, 0] = 3.0e38                        # finite but beyond the 2^30 coordinate limit
+    st = check(gpu_ctx, oracle, s)
+    assert st.triangles_skipped >= 5
+    m = swr.scenes.identity()
+    m[15] = 0.0; m[11] = 1.0                 # w = z: vertices with z = 0 divide by zero
+    s.vertices[30:33, 2] = 0.0
+    s.transform = m
+    check(gpu_ctx, oracle, s)
+
+
+def test_nan_colour_and_out_of_range_colour(gpu_ctx, oracle, swr):
+    s = swr.scenes.random_soup(100, 128, 128, 61, r_ndc=0.4, flags=0)
+    s.vertices[0:3, 4] = np.nan
+    s.vertices[3:6, 5] = 7.5
+    s.vertices[6:9, 6] = -2.0
+    check(gpu_ctx, oracle, s)
+
+
+def test_empty_scene_clears(gpu_ctx, swr):
+    v = np.zeros((0, 8), dtype=np.float32)
+    i = np.zeros((0,), dtype=np.int64)
+    c, d = gpu_ctx.render(v, i, swr.scenes.identity(), 100, 50, 0)
+    assert (c == 0).all() and np.isposinf(d).all()
+    c, d = gpu_ctx.render(v, i, swr.scenes.identity(), 100, 50, DT)
+    assert (c == 0).all() and np.isposinf(d).all()
+
+
+@pytest.mark.parametrize("w,h", [(1, 1), (3, 5), (65, 33), (64, 32), (63, 31), (130, 70)])
+def test_ragged_framebuffers(gpu_ctx, oracle, swr, w, h):
+    for flags in (0, DT):
+        s = swr.scenes.random_soup(50, w, h, 70 + w, r_ndc=0.7, flags=flags, margin=1.0)
+        check(gpu_ctx, oracle, s)
+
+
+def test_app_transform_torus_cfg2_small(gpu_ctx, oracle, swr):
+    s = swr.scenes.cfg2_teapot_scale(480, 270)
+    check(gpu_ctx, oracle, s, 0)
+    check(gpu_ctx, oracle, s, DT)
+
+
+def test_bands_assemble_to_full_frame(swr, oracle):
+    """Tile-row band sharding: two contexts, two bands, one host image."""
+    s = swr.scenes.random_soup(4000, 640, 480, 81, r_ndc=0.08, flags=DT)
+    ref_c, ref_d, _, _ = oracle.render_scene(s, oracle.TINV_PER_TRIANGLE)
+    color = np.zeros((480, 640, 4), dtype=np.uint8)
+    depth = np.zeros((480, 640), dtype=np.float32)
+    for parts in (2, 3):
+        color[:] = 7
+        depth[:] = 7
+        for k in range(parts):
+            r0, r1 = swr.band_rows(480, parts, k)
+            with swr.Context() as ctx:
+                ctx.scene_upload(s.vertices, s.indices)
+                ctx.target_set(640, 480, r0, r1)
+                ctx.draw(s.transform, s.flags)
+                ctx.read_color(color)
+                ctx.read_depth(depth)
+        assert_same(color, depth, ref_c, ref_d, f"bands={parts}")
+
+
+def test_resident_path_many_frames_and_determinism(gpu_ctx, oracle, swr):
+    """The app's frame loop (App.swift:153-185): same mesh, new transform every frame."""
+    s = swr.scenes.cfg2_teapot_scale(320, 240)
+    gpu_ctx.scene_upload(s.vertices, s.indices)
+    gpu_ctx.target_set(320, 240)
+    prev = None
+    for frame in range(4):
+        m = swr.scenes.app_transform(frame / 60.0 * 20)
+        gpu_ctx.draw(m, DT)
+        c, d = gpu_ctx.read_color(), gpu_ctx.read_depth()
+        rc, rd, _, _ = oracle.render(s.vertices, s.indices, m, 320, 240, DT | oracle.TINV_PER_TRIANGLE)
+        assert_same(c, d, rc, rd, f"frame {frame}")
+        gpu_ctx.draw(m, DT)                                   # same frame again: byte-identical
+        assert np.array_equal(c, gpu_ctx.read_color()) and np.array_equal(d.view(np.uint32), gpu_ctx.read_depth().view(np.uint32))
+        if prev is not None:
+            assert not np.array_equal(prev, c)
+        prev = c
+
+
+def test_pair_list_overflow_regrows(swr, oracle):
+    """Many screen-filling triangles: (triangle,tile) pairs exceed the initial capacity."""
+    s = swr.scenes.random_soup(300, 1920, 1080, 91, r_ndc=1.5, flags=DT, margin=0.5)
+    with swr.Context() as ctx:
+        c, d = ctx.render(s.vertices, s.indices, s.transform, s.width, s.height, s.flags)
+        t = ctx.timings()
+    rc, rd, _, _ = oracle.render_scene(s, oracle.TINV_PER_TRIANGLE)
+    assert t["tile_pairs"] > 2 * 300 + 65536
+    assert_same(c, d, rc, rd, "overflow")
+
+
+def test_error_codes(gpu_ctx, swr):
+    s = swr.scenes.cfg1_triangle()
+    with pytest.raises(swr.SwrError) as e:
+        gpu_ctx.render(s.vertices, np.array([0, 1], dtype=np.int64), s.transform, 64, 64)
+    assert e.value.code == -2                                  # index_count % 3 (Renderer.swift:209)
+    with pytest.raises(swr.SwrError) as e:
+        gpu_ctx.render(s.vertices, np.array([0, 1, 3], dtype=np.int64), s.transform, 64, 64)
+    assert e.value.code == -3
+    with pytest.raises(swr.SwrError) as e:
+        gpu_ctx.render(s.vertices, np.array([0, -1, 2], dtype=np.int64), s.transform, 64, 64)
+    assert e.value.code == -3
+    with pytest.raises(swr.SwrError) as e:
+        gpu_ctx.render(s.vertices, s.indices, s.transform, 64, 64, primitive_type=1)
+    assert e.value.code == -5                                  # .line is a stub in the reference
+    with pytest.raises(swr.SwrError) as e:
+        gpu_ctx.render(s.vertices, s.indices, s.transform, 0, 64)
+    assert e.value.code == -1
+    # the context stays usable after errors
+    c, _ = gpu_ctx.render(s.vertices, s.indices, s.transform, 256, 256, 0)
+    assert (c[..., 3] == 255).sum() == 8193
+
+
+def test_golden_fixtures_on_gpu(gpu_ctx):
+    """The committed golden vectors (tests/golden/*.npz, made by make_golden.py from the oracle)."""
+    import glob
+    import os
+    files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+    assert files
+    for f in files:
+        g = np.load(f)
+        c, d = gpu_ctx.render(g["vertices"], g["indices"], g["transform"], int(g["width"]), int(g["height"]), int(g["flags"]))
+        assert_same(c, d, g["color"] if "color" in g.files else None, g["depth"], os.path.basename(f))
+
+
+# ---- BASELINE configs at full size -------------------------------------------------------------
+def test_cfg2_full(gpu_ctx, oracle, swr):
+    s = swr.scenes.cfg2_teapot_scale()
+    check(gpu_ctx, oracle, s, 0)
+
+
+def test_cfg3_full(gpu_ctx, oracle, swr):
+    s = swr.scenes.cfg3_bunny_scale()
+    check(gpu_ctx, oracle, s)
+
+
+def test_cfg4_full_depth_only_and_colour(gpu_ctx, oracle, swr):
+    """The headline workload: 1M random triangles at 4K, z-test; full frame vs the oracle."""
+    s = swr.scenes.cfg4_soup()
+    st = check(gpu_ctx, oracle, s)                    # depth-only
+    assert st.fragments > 30_000_000
+    check(gpu_ctx, oracle, s, DT)                     # colour + depth
+    # size-independent properties at full size: permuting primitives must not change a z-tested
+    # image (except at exact depth ties, absent with random z), and depth-only == depth of colour pass
+    perm = np.argsort(swr.scenes.splitmix64(5, s.triangles))
+    idx = s.indices.reshape(-1, 3)[perm].reshape(-1)
+    _, d0 = gpu_ctx.render(s.vertices, s.indices, s.transform, s.width, s.height, DT | NC)
+    _, d1 = gpu_ctx.render(s.vertices, idx, s.transform, s.width, s.height, DT | NC)
+    assert np.array_equal(d0.view(np.uint32), d1.view(np.uint32))
+
+
+def test_cfg5_8k(gpu_ctx, oracle, swr):
+    s = swr.scenes.cfg5_sponza_scale()
+    check(gpu_ctx, oracle, s)

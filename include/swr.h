@@ -145,7 +145,11 @@ int swr_read_depth(swr_context* ctx, float* dst_full_image);
 
 /* Timing instrumentation (hipEvents on the context stream around each kernel). */
 int swr_timing_enable(swr_context* ctx, int enable);
-int swr_get_timings(swr_context* ctx, swr_timings* out);
+int swr_get_timings(swr_context* ctx, swr_timings* out);          /* the last frame */
+/* Sums over every frame drawn since swr_timing_reset (events are kept in a ring, so a whole
+ * timed region of frames is measured without a host sync per frame). */
+int swr_timing_totals(swr_context* ctx, swr_timings* sum_out, int64_t* frames_out);
+int swr_timing_reset(swr_context* ctx);
 
 /* Tile geometry the band boundaries must respect. */
 int swr_tile_rows(void);

@@ -17,7 +17,7 @@ FLAG_NO_COLOR = 2
 ABI_SYMBOLS = [
     "swr_abi_version", "swr_version", "swr_context_create", "swr_context_destroy", "swr_last_error",
     "swr_render", "swr_scene_upload", "swr_target_set", "swr_draw", "swr_sync", "swr_read_color",
-    "swr_read_depth", "swr_timing_enable", "swr_get_timings", "swr_tile_rows", "swr_tile_cols",
+    "swr_read_depth", "swr_timing_enable", "swr_get_timings", "swr_timing_totals", "swr_timing_reset", "swr_tile_rows", "swr_tile_cols",
     "swr_band_rows",
 ]
 
@@ -97,9 +97,11 @@ def load_library():
     L.swr_read_depth.argtypes = [vp, vp]
     L.swr_timing_enable.argtypes = [vp, ctypes.c_int]
     L.swr_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
+    L.swr_timing_totals.argtypes = [vp, ctypes.POINTER(Timings), ctypes.POINTER(i64)]
+    L.swr_timing_reset.argtypes = [vp]
     L.swr_band_rows.argtypes = [i64, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     for name in ("swr_context_create", "swr_render", "swr_scene_upload", "swr_target_set", "swr_draw",
-                 "swr_sync", "swr_read_color", "swr_read_depth", "swr_timing_enable", "swr_get_timings",
+                 "swr_sync", "swr_read_color", "swr_read_depth", "swr_timing_enable", "swr_get_timings", "swr_timing_totals", "swr_timing_reset",
                  "swr_band_rows", "swr_tile_rows", "swr_tile_cols"):
         getattr(L, name).restype = ctypes.c_int
     _lib = L
@@ -194,6 +196,15 @@ class Context:
         t = Timings()
         self._check(self._L.swr_get_timings(self._h, ctypes.byref(t)))
         return t.as_dict()
+
+    def timing_totals(self):
+        """(sums dict, frames) over every frame since timing_reset()."""
+        t, n = Timings(), ctypes.c_int64()
+        self._check(self._L.swr_timing_totals(self._h, ctypes.byref(t), ctypes.byref(n)))
+        return t.as_dict(), n.value
+
+    def timing_reset(self):
+        self._check(self._L.swr_timing_reset(self._h))
 
     # -- one-shot path: Renderer.render(renderPass:) / GpuRenderer.render(renderPass:) -----
     def render(self, vertices, indices, transform, width, height, flags=0, primitive_type=0,

@@ -50,10 +50,17 @@ struct swr_context {
     uint32_t last_flags = 0;
     bool draw_pending = false;
 
+    // timing: a ring of hipEvent sets recorded on the context stream around each kernel, so a
+    // whole timed region of frames can be measured without a host sync per frame
+    static constexpr int RING = 64;
     bool timing = false;
-    hipEvent_t ev[5]{};
+    hipEvent_t ev[RING][5]{};
     bool ev_ok = false;
+    uint64_t seq = 0;          // frames enqueued with timing on
+    uint64_t harvested = 0;    // frames whose events have been read
     swr_timings last{};
+    double sum_ms[5]{};
+    int64_t sum_frames = 0;
 };
 
 namespace {
@@ -129,19 +136,45 @@ DeviceFrame make_frame(swr_context* c, const float m[16], uint32_t flags) {
     return f;
 }
 
+// read the events of every completed-but-unread frame (caller has synchronised the stream)
+void harvest(swr_context* c) {
+    for (; c->harvested < c->seq; c->harvested++) {
+        hipEvent_t* ev = c->ev[c->harvested % swr_context::RING];
+        float ms[5] = {0, 0, 0, 0, 0};
+        hipEventElapsedTime(&ms[0], ev[0], ev[1]);
+        hipEventElapsedTime(&ms[1], ev[1], ev[2]);
+        hipEventElapsedTime(&ms[2], ev[2], ev[3]);
+        hipEventElapsedTime(&ms[3], ev[3], ev[4]);
+        hipEventElapsedTime(&ms[4], ev[0], ev[4]);
+        c->last.setup_bin_ms = ms[0]; c->last.scan_ms = ms[1]; c->last.scatter_ms = ms[2];
+        c->last.raster_ms = ms[3]; c->last.total_ms = ms[4];
+        for (int i = 0; i < 5; i++) c->sum_ms[i] += ms[i];
+        c->sum_frames++;
+    }
+}
+
 int enqueue_frame(swr_context* c) {
     DeviceFrame f = make_frame(c, c->last_m, c->last_flags);
+    hipEvent_t* ev = nullptr;
+    if (c->timing) {
+        if (c->seq - c->harvested >= (uint64_t)swr_context::RING) {   // ring full: drain it
+            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            harvest(c);
+        }
+        ev = c->ev[c->seq % swr_context::RING];
+        c->seq++;
+    }
     const size_t zero_bytes = (size_t)(CNT_WORDS + tiles_of(c->tg)) * 4;
     HIP_TRY(c, hipMemsetAsync(c->tilebuf.p, 0, zero_bytes, c->stream));
-    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[0], c->stream));
+    if (ev) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     launch_setup_bin(f, c->stream);
-    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[1], c->stream));
+    if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     launch_scan(f, c->stream);
-    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[2], c->stream));
+    if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     launch_scatter(f, c->stream);
-    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[3], c->stream));
+    if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     launch_raster(f, c->stream);
-    if (c->timing) HIP_TRY(c, hipEventRecord(c->ev[4], c->stream));
+    if (ev) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_counters, f.counters, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
     c->draw_pending = true;
@@ -191,7 +224,8 @@ int swr_context_create(const swr_config* cfg, swr_context** out) {
         return rc;
     }
     memset(c->h_counters, 0, CNT_WORDS * 4);
-    for (int i = 0; i < 5; i++) hipEventCreate(&c->ev[i]);
+    for (int r = 0; r < swr_context::RING; r++)
+        for (int i = 0; i < 5; i++) hipEventCreate(&c->ev[r][i]);
     c->ev_ok = true;
     *out = c;
     return SWR_OK;
@@ -205,7 +239,9 @@ void swr_context_destroy(swr_context* c) {
                       &c->pair_tile, &c->pair_slot, &c->pair_prim, &c->bins};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_counters) hipHostFree(c->h_counters);
-    if (c->ev_ok) for (int i = 0; i < 5; i++) hipEventDestroy(c->ev[i]);
+    if (c->ev_ok)
+        for (int r = 0; r < swr_context::RING; r++)
+            for (int i = 0; i < 5; i++) hipEventDestroy(c->ev[r][i]);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -291,23 +327,14 @@ int swr_sync(swr_context* c) {
     HIP_TRY(c, hipSetDevice(c->device));
     for (int attempt = 0; attempt < 8; attempt++) {
         HIP_TRY(c, hipStreamSynchronize(c->stream));
-        if (!c->draw_pending) return SWR_OK;
+        if (!c->draw_pending) { harvest(c); return SWR_OK; }
         const uint32_t pairs = c->h_counters[CNT_PAIRS];
         if (pairs <= c->capacity) {
             c->draw_pending = false;
             c->last.tile_pairs = pairs;
             c->last.tiles = tiles_of(c->tg);
             c->last.triangles = c->ni / 3;
-            if (c->timing) {
-                float ms[5] = {0, 0, 0, 0, 0};
-                hipEventElapsedTime(&ms[0], c->ev[0], c->ev[1]);
-                hipEventElapsedTime(&ms[1], c->ev[1], c->ev[2]);
-                hipEventElapsedTime(&ms[2], c->ev[2], c->ev[3]);
-                hipEventElapsedTime(&ms[3], c->ev[3], c->ev[4]);
-                hipEventElapsedTime(&ms[4], c->ev[0], c->ev[4]);
-                c->last.setup_bin_ms = ms[0]; c->last.scan_ms = ms[1]; c->last.scatter_ms = ms[2];
-                c->last.raster_ms = ms[3]; c->last.total_ms = ms[4];
-            }
+            harvest(c);
             return SWR_OK;
         }
         // the (triangle,tile) pair list overflowed: grow and redraw the same frame
@@ -344,7 +371,30 @@ int swr_read_depth(swr_context* c, float* dst) {
 
 int swr_timing_enable(swr_context* c, int enable) {
     if (!c) return SWR_ERR_BAD_ARG;
+    int rc = swr_sync(c);
+    if (rc) return rc;
     c->timing = enable != 0;
+    return SWR_OK;
+}
+
+int swr_timing_totals(swr_context* c, swr_timings* sum, int64_t* frames) {
+    if (!c || !sum || !frames) return SWR_ERR_BAD_ARG;
+    int rc = swr_sync(c);
+    if (rc) return rc;
+    *sum = c->last;
+    sum->setup_bin_ms = (float)c->sum_ms[0]; sum->scan_ms = (float)c->sum_ms[1];
+    sum->scatter_ms = (float)c->sum_ms[2]; sum->raster_ms = (float)c->sum_ms[3];
+    sum->total_ms = (float)c->sum_ms[4];
+    *frames = c->sum_frames;
+    return SWR_OK;
+}
+
+int swr_timing_reset(swr_context* c) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    int rc = swr_sync(c);
+    if (rc) return rc;
+    for (double& v : c->sum_ms) v = 0.0;
+    c->sum_frames = 0;
     return SWR_OK;
 }
 

@@ -1,0 +1,214 @@
+"""CPU tests of the oracle (oracle/swr_oracle.c): hand-derived known answers of SURVEY.md
+Appendix C, the committed golden vectors, an independent NumPy restatement, and the invariants
+the reference's code paths imply.  PARITY UNPINNED: the reference has no
+tests or fixtures and cannot run here; these pin our reading of renderer/Renderer.swift."""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+from oracle import swr_oracle_np as onp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ---- known answers ---------------------------------------------------------------------------
+def test_kat_c1_flat_triangle(oracle, swr):
+    s = swr.scenes.cfg1_triangle()
+    c, d, st, rc = oracle.render_scene(s)
+    assert rc == 0
+    cov = c[..., 3] == 255
+    assert cov.sum() == 8193 == st.fragments
+    assert (c[cov] == (63, 127, 255, 255)).all()        # 0.25*255=63.75->63, 0.5*255=127.5->127
+    assert (c[~cov] == 0).all()
+    assert np.isposinf(d).all()                         # z-test commented out: depth never written
+    spans = {64: (128, 128), 65: (128, 128), 128: (96, 160), 191: (65, 191), 192: (64, 64)}
+    for y, (lo, hi) in spans.items():
+        xs = np.nonzero(cov[y])[0]
+        assert (xs.min(), xs.max()) == (lo, hi)          # row 192: the flat-bottom single pixel
+    assert not cov[:64].any() and not cov[193:].any()
+
+
+def test_kat_c2_gouraud(oracle, swr):
+    s = swr.scenes.cfg1_triangle(gouraud=True)
+    c, d, st, rc = oracle.render_scene(s)
+    assert tuple(c[100, 128]) == (35, 35, 183, 255)
+    assert tuple(c[150, 100]) == (141, 29, 83, 255)
+    assert tuple(c[190, 160]) == (61, 189, 3, 255)
+    c2, _, _, _ = oracle.render_scene(s, oracle.INV_RCP)
+    assert np.array_equal(c, c2)                         # both inverse variants agree on this frame
+
+
+def test_interpolate_unit(oracle):
+    """Renderer.interpolate (:467-494): segment pick, truncating division, guards."""
+    tri = [(10, 0), (0, 10), (20, 20)]
+    assert oracle.interpolate(tri, 0) == 10
+    assert oracle.interpolate(tri, 5) == 5
+    assert oracle.interpolate(tri, 10) == 0                # t >= values[1].y -> base 1
+    assert oracle.interpolate(tri, 15) == 10
+    assert oracle.interpolate(tri, 20) == 20               # base 2 -> past the end -> last x
+    assert oracle.interpolate(tri, 25) == 20
+    assert oracle.interpolate([(0, 0), (7, 3)], 1) == 2    # 7*1/3 = 2.33 -> 2
+    assert oracle.interpolate([(0, 0), (-7, 3)], 1) == -2  # truncation toward zero, not floor
+    assert oracle.interpolate([(5, 4), (9, 4)], 4) == 5    # dy == 0 -> start
+    assert oracle.interpolate([(3, 0), (3, 0), (8, 0)], 0) == 8
+    for pts in ([(10, 0), (0, 10), (20, 20)], [(0, 0), (-7, 3)], [(5, -3), (-100, 2), (7, 40)]):
+        for t in range(-5, 45):
+            assert oracle.interpolate(pts, t) == onp.interpolate(pts, t)
+
+
+def test_quantise_truncates(oracle):
+    assert oracle.quantise(1.0) == 255
+    assert oracle.quantise(0.99999994) == 254             # 1 ULP below 1.0 -> 254 (truncation)
+    assert oracle.quantise(0.5) == 127
+    assert oracle.quantise(-3.0) == 0
+    assert oracle.quantise(9.0) == 255
+    assert oracle.quantise(float("nan")) == 0
+
+
+# ---- golden vectors ---------------------------------------------------------------------------
+@pytest.mark.parametrize("path", sorted(glob.glob(os.path.join(HERE, "golden", "*.npz"))), ids=os.path.basename)
+def test_oracle_matches_golden(oracle, path):
+    g = np.load(path)
+    flags = int(g["flags"])
+    c, d, st, rc = oracle.render(g["vertices"], g["indices"], g["transform"], int(g["width"]), int(g["height"]), flags)
+    assert rc == 0 and st.fragments == int(g["fragments"]) and st.triangles_skipped == int(g["skipped"])
+    assert np.array_equal(d.view(np.uint32), g["depth"].view(np.uint32))
+    if "color" in g.files:
+        assert np.array_equal(c, g["color"])
+
+
+def test_golden_dir_has_vectors():
+    assert len(glob.glob(os.path.join(HERE, "golden", "*.npz"))) >= 8
+
+
+# ---- independent restatement ---------------------------------------------------------------------
+@pytest.mark.parametrize("seed", [1, 2, 3])
+@pytest.mark.parametrize("mode", ["painter", "ztest", "depth_only"])
+def test_c_oracle_equals_numpy_restatement(oracle, swr, seed, mode):
+    s = swr.scenes.random_soup(150, 96, 80, 1000 + seed, r_ndc=0.2, margin=1.2, shared=(seed == 3))
+    flags = {"painter": 0, "ztest": 1, "depth_only": 3}[mode]
+    c, d, st, rc = oracle.render(s.vertices, s.indices, s.transform, 96, 80, flags)
+    c2, d2, sk = onp.render(s.vertices, s.indices, s.transform, 96, 80, depth_test=bool(flags & 1), no_color=bool(flags & 2))
+    assert rc == 0 and sk == st.triangles_skipped
+    assert np.array_equal(d.view(np.uint32), d2.view(np.uint32))
+    if not flags & 2:
+        assert np.array_equal(c, c2)
+
+
+def test_numpy_restatement_with_app_transform(oracle, swr):
+    s = swr.scenes.cfg2_teapot_scale(160, 90, nu=10, nv=12)
+    c, d, st, rc = oracle.render(s.vertices, s.indices, s.transform, 160, 90, 1)
+    c2, d2, _ = onp.render(s.vertices, s.indices, s.transform, 160, 90, depth_test=True)
+    assert st.fragments > 500
+    assert np.array_equal(c, c2) and np.array_equal(d.view(np.uint32), d2.view(np.uint32))
+
+
+# ---- invariants -----------------------------------------------------------------
+@pytest.mark.parametrize("flags", [0, 1])
+def test_clamped_equals_unclamped_and_hoisted(oracle, swr, flags):
+    s = swr.scenes.random_soup(300, 128, 96, 77, r_ndc=0.25, margin=1.3)
+    a = oracle.render(s.vertices, s.indices, s.transform, 128, 96, flags)
+    b = oracle.render(s.vertices, s.indices, s.transform, 128, 96, flags | oracle.UNCLAMPED)
+    h = oracle.render(s.vertices, s.indices, s.transform, 128, 96, flags | oracle.TINV_PER_TRIANGLE)
+    for other in (b, h):
+        assert np.array_equal(a[0], other[0]) and np.array_equal(a[1].view(np.uint32), other[1].view(np.uint32))
+    assert a[2].fragments == b[2].fragments == h[2].fragments
+
+
+def test_as_written_invariants(oracle, swr):
+    s = swr.scenes.random_soup(400, 200, 150, 5, r_ndc=0.1)
+    c, d, st, _ = oracle.render_scene(s)
+    assert np.isposinf(d).all()
+    touched = c[..., 3] != 0
+    assert (c[touched][:, 3] == 255).all() and (c[~touched] == 0).all()
+    assert st.fragments_written == st.fragments
+
+
+def test_shared_edge_double_coverage(oracle, swr):
+    """No top-left rule: both triangles of a quad draw the diagonal."""
+    xyz = np.array([[-0.5, 0.5, 0.5], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [-0.5, -0.5, 0.5]], dtype=np.float32)
+    rgb = np.ones((4, 3), dtype=np.float32)
+    v = swr.scenes.pack_vertices(xyz, rgb)
+    m = swr.scenes.identity()
+    _, _, st0, _ = oracle.render(v, np.array([0, 1, 2], dtype=np.int64), m, 64, 64, 0)
+    _, _, st1, _ = oracle.render(v, np.array([0, 2, 3], dtype=np.int64), m, 64, 64, 0)
+    c, _, st, _ = oracle.render(v, np.array([0, 1, 2, 0, 2, 3], dtype=np.int64), m, 64, 64, 0)
+    assert st.fragments == st0.fragments + st1.fragments
+    assert (c[..., 3] == 255).sum() < st.fragments          # overlap on the shared diagonal
+
+
+def test_painter_vs_z_order(oracle, swr):
+    xyz = np.array([[0.0, 0.8, 0.2], [0.8, -0.8, 0.2], [-0.8, -0.8, 0.2],
+                    [0.0, 0.8, 0.7], [0.8, -0.8, 0.7], [-0.8, -0.8, 0.7]], dtype=np.float32)
+    rgb = np.array([[1, 0, 0]] * 3 + [[0, 0, 1]] * 3, dtype=np.float32)
+    v = swr.scenes.pack_vertices(xyz, rgb)
+    idx = np.arange(6, dtype=np.int64)
+    c0, _, _, _ = oracle.render(v, idx, swr.scenes.identity(), 100, 100, 0)
+    c1, d1, _, _ = oracle.render(v, idx, swr.scenes.identity(), 100, 100, 1)
+    assert tuple(c0[50, 50]) == (255, 0, 0, 255)           # far blue drawn last wins (as written)
+    assert tuple(c1[50, 50]) == (0, 0, 255, 255)           # near red wins with the z-test
+    assert d1[50, 50] == np.float32(0.2)
+
+
+def test_z_mode_permutation_invariance(oracle, swr):
+    s = swr.scenes.random_soup(500, 160, 120, 9, r_ndc=0.12, flags=1)
+    c, d, _, _ = oracle.render_scene(s)
+    perm = np.argsort(swr.scenes.splitmix64(3, s.triangles))
+    idx = s.indices.reshape(-1, 3)[perm].reshape(-1)
+    c2, d2, _, _ = oracle.render(s.vertices, idx, s.transform, 160, 120, 1)
+    assert np.array_equal(d.view(np.uint32), d2.view(np.uint32))
+    assert np.array_equal(c, c2)
+
+
+def test_inverse_variant_sensitivity_bound(oracle, swr):
+    """adj/det vs adj*(1/det): few pixels, at most 1 LSB — the size of the
+    unpinned Apple-simd gap the north star's 1-LSB tolerance is reserved for."""
+    s = swr.scenes.random_soup(300, 256, 256, 13, r_ndc=0.2)
+    a, _, st, _ = oracle.render_scene(s)
+    b, _, _, _ = oracle.render_scene(s, oracle.INV_RCP)
+    diff = np.abs(a.astype(int) - b.astype(int))
+    assert diff.max() <= 1
+    assert (diff.max(axis=-1) > 0).sum() < 1e-3 * st.fragments + 50
+
+
+def test_band_rendering_assembles(oracle, swr):
+    s = swr.scenes.random_soup(400, 128, 100, 21, r_ndc=0.2, flags=1)
+    c, d, _, _ = oracle.render_scene(s)
+    c2, d2, rcs = oracle.render_threads(s, 3)
+    assert rcs == [0, 0, 0]
+    assert np.array_equal(c, c2) and np.array_equal(d.view(np.uint32), d2.view(np.uint32))
+
+
+def test_error_codes(oracle, swr):
+    s = swr.scenes.cfg1_triangle()
+    assert oracle.render(s.vertices, np.array([0, 1], dtype=np.int64), s.transform, 8, 8)[3] == -2
+    assert oracle.render(s.vertices, np.array([0, 1, 3], dtype=np.int64), s.transform, 8, 8)[3] == -3
+    assert oracle.render(s.vertices, s.indices, s.transform, 8, 8, 0, 4, 2)[3] == -1
+
+
+def test_skip_rule(oracle, swr):
+    s = swr.scenes.random_soup(10, 64, 64, 3, r_ndc=0.3)
+    s.vertices[0, 0] = np.nan
+    s.vertices[3:6, 0:2] = 0.125
+    s.vertices[6, 1] = 4e38
+    _, _, st, rc = oracle.render_scene(s)
+    assert rc == 0 and st.triangles_skipped == 3 and st.triangles_drawn == 7
+
+
+# ---- scene generators --------------------------------------------------------------------------
+def test_scene_generators_are_deterministic(swr):
+    S = swr.scenes
+    a, b = S.cfg4_soup(ntri=2000), S.cfg4_soup(ntri=2000)
+    assert np.array_equal(a.vertices, b.vertices) and a.flags == 3
+    assert S.splitmix64(0, 3).tolist() == [16294208416658607535, 7960286522194355700, 487617019471545679]
+    xy = a.vertices[:, 0:2].reshape(-1, 3, 2)
+    assert np.abs(xy).max() <= 0.98 + 0.008 + 1e-6
+    z = a.vertices[:, 2]
+    assert z.min() >= 0.05 and z.max() <= 0.95
+    assert S.cfg2_teapot_scale().triangles == 6320
+    assert S.cfg3_bunny_scale().triangles == 69451
+    assert S.cfg5_sponza_scale().triangles == 262144
+    m = S.app_transform(0.0).reshape(4, 4).T            # rows
+    assert np.allclose(m, [[2, 0, 0, 0], [0, 2, 0, 0], [0, 0, 2, 1], [0, 0, 2, 2]])

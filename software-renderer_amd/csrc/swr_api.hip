@@ -40,8 +40,8 @@ struct swr_context {
     Target tg{};
     bool has_target = false;
     DevBuf color, depth;
-    DevBuf tilebuf;            // [CNT_WORDS counters][tiles tile_count][tiles+1 tile_start]
-    DevBuf pair_tile, pair_slot, pair_prim, bins;
+    DevBuf tilebuf;            // [CNT_WORDS counters][tiles tile_count][tiles+1 tile_start][tiles cursor]
+    DevBuf ranges, bins, bin_matrix;
     uint32_t capacity = 0;
 
     uint32_t* h_counters = nullptr;   // pinned
@@ -101,9 +101,6 @@ int ensure(swr_context* c, DevBuf& b, size_t bytes) {
 int ensure_capacity(swr_context* c, uint32_t cap) {
     if (cap <= c->capacity) return SWR_OK;
     int rc;
-    if ((rc = ensure(c, c->pair_tile, (size_t)cap * 4))) return rc;
-    if ((rc = ensure(c, c->pair_slot, (size_t)cap * 4))) return rc;
-    if ((rc = ensure(c, c->pair_prim, (size_t)cap * 4))) return rc;
     if ((rc = ensure(c, c->bins, (size_t)cap * 4))) return rc;
     c->capacity = cap;
     return SWR_OK;
@@ -123,9 +120,10 @@ DeviceFrame make_frame(swr_context* c, const float m[16], uint32_t flags) {
     f.counters = tb;
     f.tile_count = tb + CNT_WORDS;
     f.tile_start = tb + CNT_WORDS + tiles_of(c->tg);
-    f.pair_tile = (uint32_t*)c->pair_tile.p;
-    f.pair_slot = (uint32_t*)c->pair_slot.p;
-    f.pair_prim = (uint32_t*)c->pair_prim.p;
+    f.tile_cursor = tb + CNT_WORDS + 2 * tiles_of(c->tg) + 1;
+    f.ranges = (uint2*)c->ranges.p;
+    f.plan = plan_binning(f.ntri, tiles_of(c->tg));
+    f.bin_matrix = (uint32_t*)c->bin_matrix.p;
     f.bins = (uint32_t*)c->bins.p;
     f.capacity = c->capacity;
     f.color = (uint8_t*)c->color.p;
@@ -154,6 +152,13 @@ void harvest(swr_context* c) {
 }
 
 int enqueue_frame(swr_context* c) {
+    {
+        const BinPlan plan = plan_binning(c->ni / 3, tiles_of(c->tg));
+        if (plan.use_lds) {
+            int rc = ensure(c, c->bin_matrix, (size_t)plan.G * (size_t)tiles_of(c->tg) * 4);
+            if (rc) return rc;
+        }
+    }
     DeviceFrame f = make_frame(c, c->last_m, c->last_flags);
     hipEvent_t* ev = nullptr;
     if (c->timing) {
@@ -171,7 +176,7 @@ int enqueue_frame(swr_context* c) {
     if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     launch_scan(f, c->stream);
     if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
-    launch_scatter(f, c->stream);
+    launch_fill(f, c->stream);
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     launch_raster(f, c->stream);
     if (ev) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
@@ -236,7 +241,7 @@ void swr_context_destroy(swr_context* c) {
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     DevBuf* bufs[] = {&c->vertices, &c->indices, &c->geo, &c->col, &c->color, &c->depth, &c->tilebuf,
-                      &c->pair_tile, &c->pair_slot, &c->pair_prim, &c->bins};
+                      &c->ranges, &c->bins, &c->bin_matrix};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_counters) hipHostFree(c->h_counters);
     if (c->ev_ok)
@@ -264,7 +269,8 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     if ((rc = ensure(c, c->indices, (size_t)index_count * 8))) return rc;
     if ((rc = ensure(c, c->geo, (size_t)(index_count / 3) * sizeof(GeomRec)))) return rc;
     if ((rc = ensure(c, c->col, (size_t)(index_count / 3) * sizeof(ColRec)))) return rc;
-    if ((rc = ensure(c, c->tilebuf, (size_t)(CNT_WORDS + 2 * std::max(1, tiles_of(c->tg)) + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->ranges, (size_t)(index_count / 3) * sizeof(uint2)))) return rc;
+    if ((rc = ensure(c, c->tilebuf, (size_t)(CNT_WORDS + 3 * std::max(1, tiles_of(c->tg)) + 1) * 4))) return rc;
     if (vertex_count)
         HIP_TRY(c, hipMemcpyAsync(c->vertices.p, vertices, (size_t)vertex_count * sizeof(swr_vertex),
                                   hipMemcpyHostToDevice, c->stream));
@@ -287,7 +293,7 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
 
 int swr_target_set(swr_context* c, int64_t width, int64_t height, int64_t row_begin, int64_t row_end) {
     if (!c) return SWR_ERR_BAD_ARG;
-    if (width <= 0 || height <= 0 || width > (1 << 24) || height > (1 << 24))
+    if (width <= 0 || height <= 0 || width > (1 << 20) || height > (1 << 20))
         return fail(c, SWR_ERR_BAD_ARG, "bad framebuffer size %lldx%lld", (long long)width, (long long)height);
     if (row_begin < 0 || row_end > height || row_begin > row_end || (row_begin % TILE_H) != 0)
         return fail(c, SWR_ERR_BAD_ARG, "bad band [%lld,%lld): row_begin must be a multiple of %d",
@@ -304,7 +310,7 @@ int swr_target_set(swr_context* c, int64_t width, int64_t height, int64_t row_be
     int rc;
     if ((rc = ensure(c, c->color, px * 4))) return rc;
     if ((rc = ensure(c, c->depth, px * 4))) return rc;
-    if ((rc = ensure(c, c->tilebuf, (size_t)(CNT_WORDS + 2 * std::max(1, tiles_of(t)) + 1) * 4))) return rc;
+    if ((rc = ensure(c, c->tilebuf, (size_t)(CNT_WORDS + 3 * std::max(1, tiles_of(t)) + 1) * 4))) return rc;
     c->tg = t;
     c->has_target = true;
     return SWR_OK;

@@ -47,6 +47,15 @@ struct Target {
 // device-side frame counters (one 32-bit word each)
 enum { CNT_PAIRS = 0, CNT_OVERFLOW = 1, CNT_BAD_INDEX = 2, CNT_WORDS = 8 };
 
+// Geometry of the LDS binning path (see plan_binning in swr_kernels.hip).
+struct BinPlan {
+    bool use_lds;
+    int G;              // workgroups = rows of the count matrix
+    int chunk;          // primitives per workgroup
+    size_t lds_bytes;   // tiles * 4
+};
+BinPlan plan_binning(int64_t ntri, int ntiles);
+
 // Everything one frame needs, all device pointers.  colour/depth are band-local: element
 // (x, y) of the full image lives at [(y - row_begin) * width + x].
 struct DeviceFrame {
@@ -59,10 +68,11 @@ struct DeviceFrame {
     uint32_t* tile_count;          // [tiles] (triangle,tile) pairs per tile
     uint32_t* tile_start;          // [tiles+1] exclusive scan of tile_count
     uint32_t* counters;            // [CNT_WORDS]
-    uint32_t* pair_tile;           // [capacity]
-    uint32_t* pair_slot;           // [capacity]
-    uint32_t* pair_prim;           // [capacity]
+    uint32_t* tile_cursor;         // [tiles] running fill position (starts as tile_start)
+    uint2* ranges;                 // [ntri] tile rectangle of each triangle (tx0|tx1<<16, ty0|ty1<<16)
     uint32_t* bins;                // [capacity] primitive ids grouped by tile
+    uint32_t* bin_matrix;          // [G][tiles] per-workgroup tile counts -> prefixes (LDS path)
+    BinPlan plan;
     uint32_t capacity;
     uint8_t* color;
     float* depth;
@@ -75,7 +85,7 @@ void launch_validate_indices(const int64_t* indices, int64_t count, int64_t vert
                              uint32_t* counters, hipStream_t s);
 void launch_setup_bin(const DeviceFrame& f, hipStream_t s);
 void launch_scan(const DeviceFrame& f, hipStream_t s);
-void launch_scatter(const DeviceFrame& f, hipStream_t s);
+void launch_fill(const DeviceFrame& f, hipStream_t s);
 void launch_raster(const DeviceFrame& f, hipStream_t s);
 
 }  // namespace swr

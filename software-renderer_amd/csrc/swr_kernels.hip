@@ -1,12 +1,15 @@
 // swr_kernels.hip — gfx950 (CDNA4, wave64) kernels of the triangle hot path.
 //
 // Pipeline of one frame (all on one stream, no host round trip):
-//   k_setup_bin   1 lane / triangle : vertex_shader x3, /w, screen map, truncation, y-sort,
-//                                     T() = inverse 2x2, 64-B GeomRec (+48-B ColRec); bbox -> tiles;
-//                                     per overlapped tile a returning atomicAdd hands out the slot,
-//                                     (tile,slot,prim) appended to the pair list
-//   k_scan        1 workgroup       : exclusive scan of the per-tile counts
-//   k_scatter     1 lane / pair     : bins[tile_start[tile]+slot] = prim   (no atomics)
+//   k_setup_hist  1 lane / triangle : vertex_shader x3, /w, screen map, truncation, y-sort,
+//                                     T() = inverse 2x2, 64-B GeomRec (+48-B ColRec); bbox -> tile
+//                                     rectangle (8 B/triangle); per-workgroup tile histogram in LDS
+//   k_colscan     16 tiles / block  : prefix of the (workgroup x tile) count matrix over workgroups
+//   k_scan        1 workgroup       : exclusive scan of the per-tile totals
+//   k_fill_lds    1 lane / triangle : bins[ds_add_rtn(cursor[tile])] = prim, cursors seeded from
+//                                     tile_start + matrix row  (no global atomics anywhere;
+//                                     k_setup_bin / k_fill = global-atomic fallback for tile tables
+//                                     that do not fit LDS)
 //   k_raster      1 workgroup / tile: 64-bit visibility keys for the tile live in LDS; every
 //                                     lane walks the scanline spans of ITS OWN triangle and
 //                                     ds_min_u64's (depth|prim) keys into the tile; big triangles
@@ -26,6 +29,7 @@
 // reference; IEEE-correct division; the same expressions in setup, raster and resolve.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "swr_internal.h"
 #include "swr_shaders.hip.h"
@@ -115,18 +119,18 @@ struct SetupArgs {
     GeomRec* geo;
     ColRec* col;            // may be null (depth-only)
     uint32_t* tile_count;
-    uint32_t* counters;
-    uint32_t* pair_tile;
-    uint32_t* pair_slot;
-    uint32_t* pair_prim;
-    uint32_t capacity;
+    uint2* ranges;
     Target tg;
     float4x4 m;
 };
 
-__global__ __launch_bounds__(256) void k_setup_bin(SetupArgs a) {
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (p >= a.ntri) return;
+constexpr uint32_t RANGE_NONE_X = 0x00000001u;   // tx0 = 1, tx1 = 0: empty rectangle
+
+// Per-triangle work of the setup stage: the three vertex_shader calls, /w, screen map,
+// truncation, y-sort, T(); writes the 64-B GeomRec (+ ColRec) and returns the rectangle of
+// tiles the triangle's bbox overlaps inside the band (RANGE_NONE_X when none).
+__device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
+    uint2 range = make_uint2(RANGE_NONE_X, 0u);
 
     // :223-227 — three vertex references of primitive p, in index order
     const int64_t i0 = a.indices[3 * p + 0];
@@ -163,11 +167,6 @@ __global__ __launch_bounds__(256) void k_setup_bin(SetupArgs a) {
     for (int k = 0; k < 3; k++)
         ok = ok && (fabsf(sx[k]) < COORD_LIMIT) && (fabsf(sy[k]) < COORD_LIMIT);
 
-    GeomRec g;
-    g.prim = (uint32_t)p;
-    g.flags = 0;
-    g.pad = 0.0f;
-    g.za = sz[0]; g.zb = sz[1]; g.zc = sz[2];
     int ix[3] = {0, 0, 0}, iy[3] = {0, 0, 0};
     if (ok) {
 #pragma unroll
@@ -179,8 +178,7 @@ __global__ __launch_bounds__(256) void k_setup_bin(SetupArgs a) {
     const float m01 = ((float)ix[1] + 0.5f) - cfx, m11 = ((float)iy[1] + 0.5f) - cfy;
     const float det = m00 * m11 - m01 * m10;
     ok = ok && (det != 0.0f) && (fabsf(det) < INFINITY);
-    g.t00 = m11 / det; g.t01 = -m01 / det; g.t10 = -m10 / det; g.t11 = m00 / det;
-    g.ax = ix[0]; g.ay = iy[0]; g.bx = ix[1]; g.by = iy[1]; g.cx = ix[2]; g.cy = iy[2];
+    const float t00 = m11 / det, t01 = -m01 / det, t10 = -m10 / det, t11 = m00 / det;
 
     // :271 stable 3-element insertion sort on FLOAT y
     int o0 = 0, o1 = 1, o2 = 2;
@@ -189,59 +187,159 @@ __global__ __launch_bounds__(256) void k_setup_bin(SetupArgs a) {
         int t = o1; o1 = o2; o2 = t;
         if (sy[o1] < sy[o0]) { t = o0; o0 = o1; o1 = t; }
     }
-    const int s0x = ix[o0], s0y = iy[o0], s1x = ix[o1], s1y = iy[o1], s2x = ix[o2], s2y = iy[o2];
-    int minx = min(ix[0], min(ix[1], ix[2])), maxx = max(ix[0], max(ix[1], ix[2]));
-    {
-        // 32-bit span arithmetic is exact when every |dx| < 2^15 and every dy < 2^16
-        const int64_t w = (int64_t)maxx - (int64_t)minx;
-        const int64_t h = (int64_t)s2y - (int64_t)s0y;
-        const bool small = (w < 32768) && (h < 65536);
-        g.flags = (ok ? GEOM_VALID : 0u) | (small ? GEOM_SMALL : 0u) |
-                  ((uint32_t)o0 << GEOM_ORD_SHIFT) | ((uint32_t)o1 << (GEOM_ORD_SHIFT + 2)) |
-                  ((uint32_t)o2 << (GEOM_ORD_SHIFT + 4));
-    }
-    (void)s0x; (void)s1x; (void)s1y; (void)s2x;
+    const int s0y = iy[o0], s2y = iy[o2];
+    const int minx = min(ix[0], min(ix[1], ix[2])), maxx = max(ix[0], max(ix[1], ix[2]));
+    // 32-bit span arithmetic is exact when every |dx| < 2^15 and every dy < 2^16
+    const bool small = ((int64_t)maxx - (int64_t)minx < 32768) && ((int64_t)s2y - (int64_t)s0y < 65536);
+    const uint32_t flags = (ok ? GEOM_VALID : 0u) | (small ? GEOM_SMALL : 0u) |
+                           ((uint32_t)o0 << GEOM_ORD_SHIFT) | ((uint32_t)o1 << (GEOM_ORD_SHIFT + 2)) |
+                           ((uint32_t)o2 << (GEOM_ORD_SHIFT + 4));
 
     // record stores: 4 x 16 B per lane
     {
         int4* gp = reinterpret_cast<int4*>(a.geo + p);
-        gp[0] = make_int4(g.ax, g.ay, g.bx, g.by);
-        gp[1] = make_int4(g.cx, g.cy, (int)g.flags, (int)g.prim);
-        reinterpret_cast<float4*>(gp)[2] = make_float4(g.t00, g.t01, g.t10, g.t11);
-        reinterpret_cast<float4*>(gp)[3] = make_float4(g.za, g.zb, g.zc, 0.0f);
+        gp[0] = make_int4(ix[0], iy[0], ix[1], iy[1]);
+        gp[1] = make_int4(ix[2], iy[2], (int)flags, (int)(uint32_t)p);
+        reinterpret_cast<float4*>(gp)[2] = make_float4(t00, t01, t10, t11);
+        reinterpret_cast<float4*>(gp)[3] = make_float4(sz[0], sz[1], sz[2], 0.0f);
         if (a.col) {
             float4* cp = reinterpret_cast<float4*>(a.col + p);
             cp[0] = ca; cp[1] = cb; cp[2] = cc;
         }
     }
-    if (!ok) return;
-
     // bbox ∩ band -> tiles.  Every covered pixel lies in [minx,maxx] x [S0.y,S2.y] (spans are
     // integer interpolants between vertex x's, :467-494).
-    int x0 = max(minx, 0), x1 = min(maxx, a.tg.width - 1);
-    int y0 = max(s0y, a.tg.row_begin), y1 = min(s2y, a.tg.row_end - 1);
-    if (x0 > x1 || y0 > y1) return;
-    const int tx0 = x0 / TILE_W, tx1 = x1 / TILE_W;
-    const int ty0 = (y0 - a.tg.row_begin) / TILE_H, ty1 = (y1 - a.tg.row_begin) / TILE_H;
-    for (int ty = ty0; ty <= ty1; ty++) {
-        for (int tx = tx0; tx <= tx1; tx++) {
-            const uint32_t tile = (uint32_t)(ty * a.tg.tiles_x + tx);
-            const uint32_t slot = atomicAdd(&a.tile_count[tile], 1u);
-            const uint32_t e = atomicAdd(&a.counters[CNT_PAIRS], 1u);   // wave-aggregated by hipcc
-            if (e < a.capacity) {
-                a.pair_tile[e] = tile;
-                a.pair_slot[e] = slot;
-                a.pair_prim[e] = (uint32_t)p;
-            }
-        }
+    const int x0 = max(minx, 0), x1 = min(maxx, a.tg.width - 1);
+    const int y0 = max(s0y, a.tg.row_begin), y1 = min(s2y, a.tg.row_end - 1);
+    if (ok && x0 <= x1 && y0 <= y1) {
+        const int tx0 = x0 / TILE_W, tx1 = x1 / TILE_W;
+        const int ty0 = (y0 - a.tg.row_begin) / TILE_H, ty1 = (y1 - a.tg.row_begin) / TILE_H;
+        range = make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
     }
+    return range;
+}
+
+// ---- binning, LDS path (default): no global atomics ------------------------------------------
+// Workgroup g owns the contiguous chunk [g*chunk, (g+1)*chunk) of the primitives in BOTH walks.
+// k_setup_hist: per-workgroup tile histogram in LDS (ds_add), written as row g of the matrix
+// M[G][tiles].  k_colscan turns every column into an exclusive prefix over g and emits the
+// per-tile totals; k_scan scans the totals; k_fill_lds seeds its LDS cursors with
+// tile_start[t] + M[g][t] and hands out bin positions with returning LDS atomics.
+__global__ __launch_bounds__(1024) void k_setup_hist(SetupArgs a, uint32_t* __restrict__ M,
+                                                     int chunk, int ntiles) {
+    extern __shared__ uint32_t hist[];
+    for (int e = threadIdx.x; e < ntiles; e += blockDim.x) hist[e] = 0u;
+    __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * chunk;
+    const int64_t p1 = min(p0 + (int64_t)chunk, a.ntri);
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+        const uint2 r = setup_triangle(a, p);
+        a.ranges[p] = r;
+        const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
+        if (tx0 <= tx1)
+            for (int ty = ty0; ty <= ty1; ty++)
+                for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&hist[ty * a.tg.tiles_x + tx], 1u);
+    }
+    __syncthreads();
+    uint32_t* row = M + (size_t)blockIdx.x * (size_t)ntiles;
+    for (int e = threadIdx.x; e < ntiles; e += blockDim.x) row[e] = hist[e];
+}
+
+// 256 threads = 16 tiles x 16 segments of the workgroup axis; G <= 16 * COLSEG.
+constexpr int COLSEG = 32;
+__global__ __launch_bounds__(256) void k_colscan(uint32_t* __restrict__ M, int G, int ntiles,
+                                                 uint32_t* __restrict__ tile_count) {
+    __shared__ uint32_t seg_sum[16][17];
+    const int el = threadIdx.x & 15, seg = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;
+    const int g0 = seg * COLSEG;
+    uint32_t v[COLSEG];
+    uint32_t sum = 0;
+#pragma unroll
+    for (int k = 0; k < COLSEG; k++) {
+        const int g = g0 + k;
+        v[k] = (e < ntiles && g < G) ? M[(size_t)g * ntiles + e] : 0u;
+    }
+#pragma unroll
+    for (int k = 0; k < COLSEG; k++) sum += v[k];
+    seg_sum[el][seg] = sum;
+    __syncthreads();
+    uint32_t run = 0;
+    for (int k = 0; k < seg; k++) run += seg_sum[el][k];
+#pragma unroll
+    for (int k = 0; k < COLSEG; k++) {
+        const int g = g0 + k;
+        if (e < ntiles && g < G) M[(size_t)g * ntiles + e] = run;
+        run += v[k];
+    }
+    if (seg == 15 && e < ntiles) tile_count[e] = run;
+}
+
+__global__ __launch_bounds__(1024) void k_fill_lds(const uint2* __restrict__ ranges, int64_t ntri,
+                                                   const uint32_t* __restrict__ M,
+                                                   const uint32_t* __restrict__ tile_start,
+                                                   const uint32_t* __restrict__ counters,
+                                                   uint32_t* __restrict__ bins, uint32_t capacity,
+                                                   int chunk, int ntiles, int tiles_x) {
+    extern __shared__ uint32_t cursor[];
+    if (counters[CNT_PAIRS] > capacity) return;   // overflow: the host grows the bins and redraws
+    const uint32_t* row = M + (size_t)blockIdx.x * (size_t)ntiles;
+    for (int e = threadIdx.x; e < ntiles; e += blockDim.x) cursor[e] = tile_start[e] + row[e];
+    __syncthreads();
+    const int64_t p0 = (int64_t)blockIdx.x * chunk;
+    const int64_t p1 = min(p0 + (int64_t)chunk, ntri);
+    for (int64_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+        const uint2 r = ranges[p];
+        const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
+        if (tx0 > tx1) continue;
+        for (int ty = ty0; ty <= ty1; ty++)
+            for (int tx = tx0; tx <= tx1; tx++) {
+                const uint32_t pos = atomicAdd(&cursor[ty * tiles_x + tx], 1u);
+                bins[pos] = (uint32_t)p;
+            }
+    }
+}
+
+// ---- binning, global-atomic path (fallback when the tile table does not fit LDS) --------------
+__global__ __launch_bounds__(256) void k_setup_bin(SetupArgs a) {
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= a.ntri) return;
+    const uint2 r = setup_triangle(a, p);
+    a.ranges[p] = r;
+    const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
+    if (tx0 > tx1) return;
+    // count pass: fire-and-forget atomics (no return value -> no round trip)
+    for (int ty = ty0; ty <= ty1; ty++)
+        for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&a.tile_count[ty * a.tg.tiles_x + tx], 1u);
+}
+
+// Second walk over the triangles' tile rectangles; a returning atomic on the tile's cursor
+// (initialised to tile_start by k_scan) hands out the bin position.  Visibility keys make the
+// raster order-independent, so bins need no particular order.
+__global__ __launch_bounds__(256) void k_fill(const uint2* __restrict__ ranges, int64_t ntri,
+                                              uint32_t* __restrict__ cursor,
+                                              const uint32_t* __restrict__ counters,
+                                              uint32_t* __restrict__ bins, uint32_t capacity,
+                                              int tiles_x) {
+    if (counters[CNT_PAIRS] > capacity) return;   // overflow: the host grows the bins and redraws
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (p >= ntri) return;
+    const uint2 r = ranges[p];
+    const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
+    if (tx0 > tx1) return;
+    for (int ty = ty0; ty <= ty1; ty++)
+        for (int tx = tx0; tx <= tx1; tx++) {
+            const uint32_t pos = atomicAdd(&cursor[ty * tiles_x + tx], 1u);
+            bins[pos] = (uint32_t)p;
+        }
 }
 
 // ------------------------------------------------------------------------------------------
 // k_scan: exclusive scan of tile_count -> tile_start[0..tiles], one workgroup
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ count,
-                                               uint32_t* __restrict__ start, int n,
+                                               uint32_t* __restrict__ start,
+                                               uint32_t* __restrict__ cursor, int n,
                                                uint32_t* counters, uint32_t capacity) {
     __shared__ uint32_t part[1024];
     const int t = threadIdx.x;
@@ -259,27 +357,12 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ coun
         __syncthreads();
     }
     uint32_t run = part[t] - s;
-    for (int i = b; i < e; i++) { start[i] = run; run += count[i]; }
+    for (int i = b; i < e; i++) { start[i] = run; cursor[i] = run; run += count[i]; }
     if (t == 1023) {
         start[n] = part[1023];
+        counters[CNT_PAIRS] = part[1023];                  // total (triangle,tile) pairs of the frame
         if (part[1023] > capacity) counters[CNT_OVERFLOW] = 1u;
     }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_scatter
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_scatter(const uint32_t* __restrict__ pair_tile,
-                                                 const uint32_t* __restrict__ pair_slot,
-                                                 const uint32_t* __restrict__ pair_prim,
-                                                 const uint32_t* __restrict__ tile_start,
-                                                 const uint32_t* __restrict__ counters,
-                                                 uint32_t* __restrict__ bins, uint32_t capacity) {
-    const uint32_t total = counters[CNT_PAIRS];
-    if (total > capacity) return;   // overflow: the host grows the buffers and redraws
-    const uint32_t stride = gridDim.x * 256u;
-    for (uint32_t e = blockIdx.x * 256u + threadIdx.x; e < total; e += stride)
-        bins[tile_start[pair_tile[e]] + pair_slot[e]] = pair_prim[e];
 }
 
 // ------------------------------------------------------------------------------------------
@@ -295,6 +378,7 @@ struct RasterArgs {
     uint8_t* color;     // band-local BGRA8
     float* depth;       // band-local f32
     Target tg;
+    int variant;        // 0 = product; >0 = timing-only ablations (SWR_DEBUG_VARIANT, results invalid)
 };
 
 constexpr unsigned long long KEY_EMPTY = ~0ull;
@@ -311,7 +395,7 @@ struct TriState {
 
 template <bool ZTEST>
 __device__ __forceinline__ void fragment(unsigned long long* keys, const TriState& t, int x, int lidx,
-                                         float r0, float r1) {
+                                         float r0, float r1, int variant = 0) {
     // setPixel (:245-269): weights at the pixel centre (x+.5, y+.5) relative to cf
     unsigned long long key;
     if (ZTEST) {
@@ -326,6 +410,10 @@ __device__ __forceinline__ void fragment(unsigned long long* keys, const TriStat
         key = ((unsigned long long)orderable_depth(d) << 32) | (unsigned long long)t.prim;
     } else {
         key = (unsigned long long)(0xFFFFFFFFu - t.prim);   // painter's order: highest prim wins
+    }
+    if (variant == 1) {   // ablation: everything but the LDS atomic
+        asm volatile("" ::"v"((uint32_t)key), "v"((uint32_t)(key >> 32)), "v"(lidx));
+        return;
     }
     atomicMin(&keys[lidx], key);
 }
@@ -402,6 +490,7 @@ __global__ __launch_bounds__(RASTER_THREADS) void k_raster(RasterArgs a) {
             big = (yb - ya + 1) * (bxb - bxa + 1) > BIG_AREA;
         }
 
+        if (a.variant == 3) { asm volatile("" ::"v"(ya), "v"(yb), "v"(t.t00), "v"(t.za), "v"(t.ch.s1x)); continue; }
         // ---- phase 1: every lane walks the spans of its own (small) triangle ----------------
         if (have && !big) {
             for (int y = ya; y <= yb; y++) {
@@ -412,7 +501,8 @@ __global__ __launch_bounds__(RASTER_THREADS) void k_raster(RasterArgs a) {
                 const float dy = ((float)y + 0.5f) - t.cfy;
                 const float r0 = t.t01 * dy, r1 = t.t11 * dy;
                 const int rowbase = (y - Y0) * TILE_W - X0;
-                for (int x = lo; x <= hi; x++) fragment<ZTEST>(keys, t, x, rowbase + x, r0, r1);
+                if (a.variant == 2) { asm volatile("" ::"v"(lo), "v"(hi), "v"(r0), "v"(r1)); continue; }
+                for (int x = lo; x <= hi; x++) fragment<ZTEST>(keys, t, x, rowbase + x, r0, r1, a.variant);
             }
         }
 
@@ -550,30 +640,70 @@ void launch_validate_indices(const int64_t* indices, int64_t count, int64_t vert
                        vertex_count, counters);
 }
 
-void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
-    if (f.ntri <= 0) return;
+static SetupArgs make_setup_args(const DeviceFrame& f) {
     SetupArgs a;
     a.vertices = f.vertices; a.indices = f.indices; a.ntri = f.ntri;
     a.geo = f.geo; a.col = (f.flags & SWR_FLAG_NO_COLOR) ? nullptr : f.col;
-    a.tile_count = f.tile_count; a.counters = f.counters;
-    a.pair_tile = f.pair_tile; a.pair_slot = f.pair_slot; a.pair_prim = f.pair_prim;
-    a.capacity = f.capacity; a.tg = f.tg;
+    a.tile_count = f.tile_count; a.ranges = f.ranges; a.tg = f.tg;
     for (int c = 0; c < 4; c++)
         a.m.columns[c] = make_float4(f.m[4 * c + 0], f.m[4 * c + 1], f.m[4 * c + 2], f.m[4 * c + 3]);
-    const unsigned blocks = (unsigned)((f.ntri + 255) / 256);
-    hipLaunchKernelGGL(k_setup_bin, dim3(blocks), dim3(256), 0, s, a);
+    return a;
+}
+
+// LDS binning geometry: G workgroups of 1024 threads, each owning `chunk` consecutive primitives.
+BinPlan plan_binning(int64_t ntri, int ntiles) {
+    BinPlan p{};
+    p.lds_bytes = (size_t)ntiles * 4;
+    const char* force = getenv("SWR_BIN_MODE");
+    p.use_lds = p.lds_bytes <= 144 * 1024 && !(force && force[0] == 'a');   // 'atomic' forces the fallback
+    int64_t g = (ntri + 1023) / 1024;
+    if (g > 16 * COLSEG) g = 16 * COLSEG;
+    if (g < 1) g = 1;
+    p.G = (int)g;
+    p.chunk = (int)((ntri + g - 1) / g);
+    if (p.chunk < 1) p.chunk = 1;
+    return p;
+}
+
+void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
+    if (f.ntri <= 0) return;
+    const SetupArgs a = make_setup_args(f);
+    const int ntiles = f.tg.tiles_x * f.tg.tiles_y;
+    if (f.plan.use_lds) {
+        static bool attr_set = false;
+        if (!attr_set) {
+            (void)hipFuncSetAttribute((const void*)k_setup_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_fill_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            attr_set = true;
+        }
+        hipLaunchKernelGGL(k_setup_hist, dim3(f.plan.G), dim3(1024), f.plan.lds_bytes, s, a, f.bin_matrix,
+                           f.plan.chunk, ntiles);
+        hipLaunchKernelGGL(k_colscan, dim3((ntiles + 15) / 16), dim3(256), 0, s, f.bin_matrix, f.plan.G, ntiles,
+                           f.tile_count);
+    } else {
+        const unsigned blocks = (unsigned)((f.ntri + 255) / 256);
+        hipLaunchKernelGGL(k_setup_bin, dim3(blocks), dim3(256), 0, s, a);
+    }
 }
 
 void launch_scan(const DeviceFrame& f, hipStream_t s) {
     const int n = f.tg.tiles_x * f.tg.tiles_y;
-    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, f.tile_count, f.tile_start, n, f.counters,
-                       f.capacity);
+    hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, f.tile_count, f.tile_start, f.tile_cursor, n,
+                       f.counters, f.capacity);
 }
 
-void launch_scatter(const DeviceFrame& f, hipStream_t s) {
+void launch_fill(const DeviceFrame& f, hipStream_t s) {
     if (f.ntri <= 0) return;
-    hipLaunchKernelGGL(k_scatter, dim3(2048), dim3(256), 0, s, f.pair_tile, f.pair_slot, f.pair_prim,
-                       f.tile_start, f.counters, f.bins, f.capacity);
+    const int ntiles = f.tg.tiles_x * f.tg.tiles_y;
+    if (f.plan.use_lds) {
+        hipLaunchKernelGGL(k_fill_lds, dim3(f.plan.G), dim3(1024), f.plan.lds_bytes, s, f.ranges, f.ntri,
+                           f.bin_matrix, f.tile_start, f.counters, f.bins, f.capacity, f.plan.chunk, ntiles,
+                           f.tg.tiles_x);
+    } else {
+        const unsigned blocks = (unsigned)((f.ntri + 255) / 256);
+        hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, s, f.ranges, f.ntri, f.tile_cursor, f.counters,
+                           f.bins, f.capacity, f.tg.tiles_x);
+    }
 }
 
 void launch_raster(const DeviceFrame& f, hipStream_t s) {
@@ -582,6 +712,8 @@ void launch_raster(const DeviceFrame& f, hipStream_t s) {
     a.counters = f.counters; a.capacity = f.capacity;
     a.color = (f.flags & SWR_FLAG_NO_COLOR) ? nullptr : f.color;
     a.depth = f.depth; a.tg = f.tg;
+    static const int variant = getenv("SWR_DEBUG_VARIANT") ? atoi(getenv("SWR_DEBUG_VARIANT")) : 0;
+    a.variant = variant;
     const unsigned tiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
     if (tiles == 0) return;
     if (f.flags & SWR_FLAG_DEPTH_TEST)

@@ -304,3 +304,12 @@ def test_cfg4_full_depth_only_and_colour(gpu_ctx, oracle, swr):
 def test_cfg5_8k(gpu_ctx, oracle, swr):
     s = swr.scenes.cfg5_sponza_scale()
     check(gpu_ctx, oracle, s)
+
+
+def test_global_atomic_binning_fallback(swr, oracle, monkeypatch):
+    """The binning path used when the tile table does not fit LDS (forced via SWR_BIN_MODE)."""
+    monkeypatch.setenv("SWR_BIN_MODE", "atomic")
+    for flags in (0, DT):
+        s = swr.scenes.random_soup(5000, 900, 500, 123, r_ndc=0.05, flags=flags, margin=1.1)
+        with swr.Context() as ctx:
+            check(ctx, oracle, s)

@@ -293,7 +293,7 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
 
 int swr_target_set(swr_context* c, int64_t width, int64_t height, int64_t row_begin, int64_t row_end) {
     if (!c) return SWR_ERR_BAD_ARG;
-    if (width <= 0 || height <= 0 || width > (1 << 20) || height > (1 << 20))
+    if (width <= 0 || height <= 0 || width > 65535 || height > 65535)
         return fail(c, SWR_ERR_BAD_ARG, "bad framebuffer size %lldx%lld", (long long)width, (long long)height);
     if (row_begin < 0 || row_end > height || row_begin > row_end || (row_begin % TILE_H) != 0)
         return fail(c, SWR_ERR_BAD_ARG, "bad band [%lld,%lld): row_begin must be a multiple of %d",

@@ -69,7 +69,7 @@ struct DeviceFrame {
     uint32_t* tile_start;          // [tiles+1] exclusive scan of tile_count
     uint32_t* counters;            // [CNT_WORDS]
     uint32_t* tile_cursor;         // [tiles] running fill position (starts as tile_start)
-    uint2* ranges;                 // [ntri] tile rectangle of each triangle (tx0|tx1<<16, ty0|ty1<<16)
+    uint2* ranges;                 // [ntri] band-clipped pixel bbox (x0|x1<<16, y0|y1<<16, y band-relative)
     uint32_t* bins;                // [capacity] primitive ids grouped by tile
     uint32_t* bin_matrix;          // [G][tiles] per-workgroup tile counts -> prefixes (LDS path)
     BinPlan plan;

@@ -94,6 +94,23 @@ __device__ __forceinline__ void row_span(const Chains& c, int y, int& lo, int& h
     hi = L < R ? R : L;
 }
 
+// row_span for triangles flagged GEOM_SMALL only (phase 1 of k_raster): no 64-bit path.
+__device__ __forceinline__ void row_span_small(const Chains& c, int y, int& lo, int& hi) {
+    const bool last = y >= c.s2y;
+    const bool seg1 = y >= c.s1y;
+    const int x0 = last ? c.s2x : (seg1 ? c.s1x : c.s0x);
+    const int y0 = seg1 ? c.s1y : c.s0y;
+    const int dx = last ? 0 : (seg1 ? c.s2x - c.s1x : c.s1x - c.s0x);
+    const int dy = last ? 1 : (seg1 ? c.s2y - c.s1y : c.s1y - c.s0y);
+    const float rd = last ? 1.0f : (seg1 ? c.r12 : c.r01);
+    const int dyr = c.s2y - c.s0y;
+    const int dxr = dyr ? c.s2x - c.s0x : 0;
+    const int L = x0 + tdiv_small(dx * (y - y0), dy, rd);
+    const int R = c.s0x + tdiv_small(dxr * (y - c.s0y), dyr ? dyr : 1, dyr ? c.r02 : 1.0f);
+    lo = min(L, R);
+    hi = max(L, R);
+}
+
 // ------------------------------------------------------------------------------------------
 // index validation (Swift would trap on an out-of-range index, Renderer.swift:226)
 // ------------------------------------------------------------------------------------------
@@ -127,8 +144,9 @@ struct SetupArgs {
 constexpr uint32_t RANGE_NONE_X = 0x00000001u;   // tx0 = 1, tx1 = 0: empty rectangle
 
 // Per-triangle work of the setup stage: the three vertex_shader calls, /w, screen map,
-// truncation, y-sort, T(); writes the 64-B GeomRec (+ ColRec) and returns the rectangle of
-// tiles the triangle's bbox overlaps inside the band (RANGE_NONE_X when none).
+// truncation, y-sort, T(); writes the 64-B GeomRec (+ ColRec) and returns the triangle's bbox
+// clipped to the band, in pixels: x = x0 | x1 << 16, y = (y0 - row_begin) | (y1 - row_begin) << 16
+// (RANGE_NONE_X when the bbox misses the band).
 __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
     uint2 range = make_uint2(RANGE_NONE_X, 0u);
 
@@ -211,12 +229,30 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
     // integer interpolants between vertex x's, :467-494).
     const int x0 = max(minx, 0), x1 = min(maxx, a.tg.width - 1);
     const int y0 = max(s0y, a.tg.row_begin), y1 = min(s2y, a.tg.row_end - 1);
-    if (ok && x0 <= x1 && y0 <= y1) {
-        const int tx0 = x0 / TILE_W, tx1 = x1 / TILE_W;
-        const int ty0 = (y0 - a.tg.row_begin) / TILE_H, ty1 = (y1 - a.tg.row_begin) / TILE_H;
-        range = make_uint2((uint32_t)tx0 | ((uint32_t)tx1 << 16), (uint32_t)ty0 | ((uint32_t)ty1 << 16));
-    }
+    if (ok && x0 <= x1 && y0 <= y1)
+        range = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16),
+                           (uint32_t)(y0 - a.tg.row_begin) | ((uint32_t)(y1 - a.tg.row_begin) << 16));
     return range;
+}
+
+// Bin entries carry a 6-bit size class above the primitive id (when ids fit 26 bits): the number
+// of rows of the triangle inside the tile minus one (0..31), or CLASS_BIG when its clipped bbox
+// area exceeds BIG_AREA.  k_raster counting-sorts its bin by this key so that the 64 triangles a
+// wave walks together have the same height.
+constexpr int BIG_AREA = 384;   // clipped bbox area above which a triangle is walked by the whole wave
+constexpr uint32_t CLASS_SHIFT = 26;
+constexpr uint32_t CLASS_BIG = 32;
+constexpr int NUM_CLASSES = 33;
+static_assert(TILE_H <= 32, "row-count classes assume TILE_H <= 32");
+
+struct PixBox { int x0, x1, y0, y1; };   // y relative to the band
+__device__ __forceinline__ PixBox unpack_box(uint2 r) {
+    PixBox b; b.x0 = r.x & 0xFFFF; b.x1 = r.x >> 16; b.y0 = r.y & 0xFFFF; b.y1 = r.y >> 16; return b;
+}
+__device__ __forceinline__ uint32_t size_class(const PixBox& b, int tx, int ty) {
+    const int rows = min(b.y1, ty * TILE_H + TILE_H - 1) - max(b.y0, ty * TILE_H) + 1;
+    const int cols = min(b.x1, tx * TILE_W + TILE_W - 1) - max(b.x0, tx * TILE_W) + 1;
+    return rows * cols > BIG_AREA ? CLASS_BIG : (uint32_t)(rows - 1);
 }
 
 // ---- binning, LDS path (default): no global atomics ------------------------------------------
@@ -235,10 +271,11 @@ __global__ __launch_bounds__(1024) void k_setup_hist(SetupArgs a, uint32_t* __re
     for (int64_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
         const uint2 r = setup_triangle(a, p);
         a.ranges[p] = r;
-        const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
-        if (tx0 <= tx1)
-            for (int ty = ty0; ty <= ty1; ty++)
-                for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&hist[ty * a.tg.tiles_x + tx], 1u);
+        const PixBox b = unpack_box(r);
+        if (b.x0 <= b.x1)
+            for (int ty = b.y0 / TILE_H; ty <= b.y1 / TILE_H; ty++)
+                for (int tx = b.x0 / TILE_W; tx <= b.x1 / TILE_W; tx++)
+                    atomicAdd(&hist[ty * a.tg.tiles_x + tx], 1u);
     }
     __syncthreads();
     uint32_t* row = M + (size_t)blockIdx.x * (size_t)ntiles;
@@ -280,7 +317,7 @@ __global__ __launch_bounds__(1024) void k_fill_lds(const uint2* __restrict__ ran
                                                    const uint32_t* __restrict__ tile_start,
                                                    const uint32_t* __restrict__ counters,
                                                    uint32_t* __restrict__ bins, uint32_t capacity,
-                                                   int chunk, int ntiles, int tiles_x) {
+                                                   int chunk, int ntiles, int tiles_x, int tag_class) {
     extern __shared__ uint32_t cursor[];
     if (counters[CNT_PAIRS] > capacity) return;   // overflow: the host grows the bins and redraws
     const uint32_t* row = M + (size_t)blockIdx.x * (size_t)ntiles;
@@ -289,13 +326,12 @@ __global__ __launch_bounds__(1024) void k_fill_lds(const uint2* __restrict__ ran
     const int64_t p0 = (int64_t)blockIdx.x * chunk;
     const int64_t p1 = min(p0 + (int64_t)chunk, ntri);
     for (int64_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
-        const uint2 r = ranges[p];
-        const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
-        if (tx0 > tx1) continue;
-        for (int ty = ty0; ty <= ty1; ty++)
-            for (int tx = tx0; tx <= tx1; tx++) {
+        const PixBox b = unpack_box(ranges[p]);
+        if (b.x0 > b.x1) continue;
+        for (int ty = b.y0 / TILE_H; ty <= b.y1 / TILE_H; ty++)
+            for (int tx = b.x0 / TILE_W; tx <= b.x1 / TILE_W; tx++) {
                 const uint32_t pos = atomicAdd(&cursor[ty * tiles_x + tx], 1u);
-                bins[pos] = (uint32_t)p;
+                bins[pos] = (uint32_t)p | (tag_class ? size_class(b, tx, ty) << CLASS_SHIFT : 0u);
             }
     }
 }
@@ -306,11 +342,12 @@ __global__ __launch_bounds__(256) void k_setup_bin(SetupArgs a) {
     if (p >= a.ntri) return;
     const uint2 r = setup_triangle(a, p);
     a.ranges[p] = r;
-    const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
-    if (tx0 > tx1) return;
+    const PixBox b = unpack_box(r);
+    if (b.x0 > b.x1) return;
     // count pass: fire-and-forget atomics (no return value -> no round trip)
-    for (int ty = ty0; ty <= ty1; ty++)
-        for (int tx = tx0; tx <= tx1; tx++) atomicAdd(&a.tile_count[ty * a.tg.tiles_x + tx], 1u);
+    for (int ty = b.y0 / TILE_H; ty <= b.y1 / TILE_H; ty++)
+        for (int tx = b.x0 / TILE_W; tx <= b.x1 / TILE_W; tx++)
+            atomicAdd(&a.tile_count[ty * a.tg.tiles_x + tx], 1u);
 }
 
 // Second walk over the triangles' tile rectangles; a returning atomic on the tile's cursor
@@ -320,17 +357,16 @@ __global__ __launch_bounds__(256) void k_fill(const uint2* __restrict__ ranges, 
                                               uint32_t* __restrict__ cursor,
                                               const uint32_t* __restrict__ counters,
                                               uint32_t* __restrict__ bins, uint32_t capacity,
-                                              int tiles_x) {
+                                              int tiles_x, int tag_class) {
     if (counters[CNT_PAIRS] > capacity) return;   // overflow: the host grows the bins and redraws
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (p >= ntri) return;
-    const uint2 r = ranges[p];
-    const int tx0 = r.x & 0xFFFF, tx1 = r.x >> 16, ty0 = r.y & 0xFFFF, ty1 = r.y >> 16;
-    if (tx0 > tx1) return;
-    for (int ty = ty0; ty <= ty1; ty++)
-        for (int tx = tx0; tx <= tx1; tx++) {
+    const PixBox b = unpack_box(ranges[p]);
+    if (b.x0 > b.x1) return;
+    for (int ty = b.y0 / TILE_H; ty <= b.y1 / TILE_H; ty++)
+        for (int tx = b.x0 / TILE_W; tx <= b.x1 / TILE_W; tx++) {
             const uint32_t pos = atomicAdd(&cursor[ty * tiles_x + tx], 1u);
-            bins[pos] = (uint32_t)p;
+            bins[pos] = (uint32_t)p | (tag_class ? size_class(b, tx, ty) << CLASS_SHIFT : 0u);
         }
 }
 
@@ -378,16 +414,16 @@ struct RasterArgs {
     uint8_t* color;     // band-local BGRA8
     float* depth;       // band-local f32
     Target tg;
-    int variant;        // 0 = product; >0 = timing-only ablations (SWR_DEBUG_VARIANT, results invalid)
+    int tag_class;      // bin entries carry a size class above bit CLASS_SHIFT
 };
 
 constexpr unsigned long long KEY_EMPTY = ~0ull;
-constexpr int BIG_AREA = 384;   // clipped bbox area above which a triangle is walked by the whole wave
 
 // Per-lane triangle state for the span walk.
 struct TriState {
     Chains ch;
     float cfx, cfy;            // float(C) + 0.5 (:89)
+    int cx;                    // C.x (integer), for the exact small-coordinate dx
     float t00, t01, t10, t11;
     float za, zb, zc;
     uint32_t prim;
@@ -395,7 +431,7 @@ struct TriState {
 
 template <bool ZTEST>
 __device__ __forceinline__ void fragment(unsigned long long* keys, const TriState& t, int x, int lidx,
-                                         float r0, float r1, int variant = 0) {
+                                         float r0, float r1) {
     // setPixel (:245-269): weights at the pixel centre (x+.5, y+.5) relative to cf
     unsigned long long key;
     if (ZTEST) {
@@ -410,10 +446,6 @@ __device__ __forceinline__ void fragment(unsigned long long* keys, const TriStat
         key = ((unsigned long long)orderable_depth(d) << 32) | (unsigned long long)t.prim;
     } else {
         key = (unsigned long long)(0xFFFFFFFFu - t.prim);   // painter's order: highest prim wins
-    }
-    if (variant == 1) {   // ablation: everything but the LDS atomic
-        asm volatile("" ::"v"((uint32_t)key), "v"((uint32_t)(key >> 32)), "v"(lidx));
-        return;
     }
     atomicMin(&keys[lidx], key);
 }
@@ -441,6 +473,7 @@ __device__ __forceinline__ void load_tri(const GeomRec* __restrict__ geo, uint32
     t.ch.r02 = __builtin_amdgcn_rcpf((float)(t.ch.s2y - t.ch.s0y));
     t.cfx = (float)q1.x + 0.5f;
     t.cfy = (float)q1.y + 0.5f;
+    t.cx = q1.x;
     t.t00 = q2.x; t.t01 = q2.y; t.t10 = q2.z; t.t11 = q2.w;
     t.za = q3.x; t.zb = q3.y; t.zc = q3.z;
     t.prim = prim;
@@ -453,8 +486,43 @@ __device__ __forceinline__ float bcast_f(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
-template <bool ZTEST>
+// ---- wave64 scans on DPP (all 64 lanes must be active) ---------------------------------------
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp0(int v) {
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xF, false);   // lanes without a source get 0
+}
+__device__ __forceinline__ int wave_incl_add(int v) {
+    v += dpp0<0x111, 0xF>(v);   // row_shr:1
+    v += dpp0<0x112, 0xF>(v);   // row_shr:2
+    v += dpp0<0x114, 0xF>(v);   // row_shr:4
+    v += dpp0<0x118, 0xF>(v);   // row_shr:8   -> inclusive scan inside each row of 16
+    v += dpp0<0x142, 0xA>(v);   // row_bcast:15 into rows 1,3
+    v += dpp0<0x143, 0xC>(v);   // row_bcast:31 into rows 2,3
+    return v;
+}
+__device__ __forceinline__ int wave_incl_max(int v) {   // v >= 0
+    v = max(v, dpp0<0x111, 0xF>(v));
+    v = max(v, dpp0<0x112, 0xF>(v));
+    v = max(v, dpp0<0x114, 0xF>(v));
+    v = max(v, dpp0<0x118, 0xF>(v));
+    v = max(v, dpp0<0x142, 0xA>(v));
+    v = max(v, dpp0<0x143, 0xC>(v));
+    return v;
+}
+__device__ __forceinline__ int pull_i(int byte_addr, int v) { return __builtin_amdgcn_ds_bpermute(byte_addr, v); }
+__device__ __forceinline__ float pull_f(int byte_addr, float v) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
+}
+
+// VAR > 0: timing-only ablations selected with SWR_DEBUG_VARIANT (results invalid):
+//   1 = no LDS atomic, 2 = no pulls/maths/atomic, 3 = no dense loop, 4 = no row walk at all
+template <bool ZTEST, int VAR = 0>
 __global__ __launch_bounds__(RASTER_THREADS) void k_raster(RasterArgs a) {
+    constexpr int SUPER = 2;   // dense steps whose owner search is done together
+    constexpr int SORT_CAP = 4 * RASTER_THREADS;   // bin entries sorted per pass
+    __shared__ uint32_t sorted[SORT_CAP];
+    __shared__ uint32_t cls_cnt[NUM_CLASSES + 1];
+    __shared__ uint32_t span_mark[RASTER_THREADS / 64][64 * SUPER];
     __shared__ unsigned long long keys[TILE_W * TILE_H];
 
     const int tile = blockIdx.x;
@@ -468,41 +536,157 @@ __global__ __launch_bounds__(RASTER_THREADS) void k_raster(RasterArgs a) {
 
     // clear fused into the LDS init (Renderer.clear :205-206, :232-236)
     for (int i = tid; i < TILE_W * TILE_H; i += RASTER_THREADS) keys[i] = KEY_EMPTY;
+    for (int i = lane; i < 64 * SUPER; i += 64) span_mark[tid >> 6][i] = 0u;
+    int tag = 0;               // marker generation of this wave (25 bits: never wraps in one launch)
     __syncthreads();
 
     const bool overflow = a.counters[CNT_PAIRS] > a.capacity;
     const uint32_t b0 = overflow ? 0u : a.tile_start[tile];
     const uint32_t b1 = overflow ? 0u : a.tile_start[tile + 1];
 
-    for (uint32_t base = b0; base < b1; base += RASTER_THREADS) {
+    const uint32_t n_all = b1 - b0;
+    for (uint32_t seg = 0; seg < n_all; seg += SORT_CAP) {
+    const uint32_t m = min((uint32_t)SORT_CAP, n_all - seg);
+    // ---- counting sort of (this segment of) the bin by size class, heaviest class first -------
+    // so that the 64 triangles a wave walks together have the same number of rows in the tile
+    if (tid <= NUM_CLASSES) cls_cnt[tid] = 0u;
+    __syncthreads();
+    {
+        uint32_t ent[SORT_CAP / RASTER_THREADS], pos[SORT_CAP / RASTER_THREADS];
+#pragma unroll
+        for (int k = 0; k < SORT_CAP / RASTER_THREADS; k++) {
+            const uint32_t i = tid + k * RASTER_THREADS;
+            ent[k] = 0u; pos[k] = 0u;
+            if (i < m) {
+                ent[k] = a.bins[b0 + seg + i];
+                pos[k] = atomicAdd(&cls_cnt[a.tag_class ? ent[k] >> CLASS_SHIFT : 0u], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {   // wave 0: exclusive prefix over the classes in descending order
+            const int c = NUM_CLASSES - 1 - tid;
+            const uint32_t v = c >= 0 ? cls_cnt[c] : 0u;
+            const uint32_t incl = (uint32_t)wave_incl_add((int)v);
+            if (c >= 0) cls_cnt[c] = incl - v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SORT_CAP / RASTER_THREADS; k++) {
+            const uint32_t i = tid + k * RASTER_THREADS;
+            if (i < m) {
+                const uint32_t c = a.tag_class ? ent[k] >> CLASS_SHIFT : 0u;
+                sorted[cls_cnt[c] + pos[k]] = a.tag_class ? ent[k] & ((1u << CLASS_SHIFT) - 1u) : ent[k];
+            }
+        }
+        __syncthreads();
+    }
+    for (uint32_t base = 0; base < m; base += RASTER_THREADS) {
         const uint32_t e = base + tid;
-        const bool have = e < b1;
+        const bool have = e < m;
         TriState t;
         int ya = 1, yb = 0, bxa = 0, bxb = -1;
         bool big = false;
         if (have) {
             int minx, maxx;
-            load_tri(a.geo, a.bins[e], t, minx, maxx);
+            load_tri(a.geo, sorted[e], t, minx, maxx);
             ya = max(t.ch.s0y, Y0);
             yb = min(t.ch.s2y, Y1);
             bxa = max(minx, X0);
             bxb = min(maxx, X1);
-            big = (yb - ya + 1) * (bxb - bxa + 1) > BIG_AREA;
+            // the dense path below needs the exact small-coordinate arithmetic; everything else
+            // (huge extents, large clipped area) is walked cooperatively in phase 2
+            big = !t.ch.small || (yb - ya + 1) * (bxb - bxa + 1) > BIG_AREA;
         }
 
-        if (a.variant == 3) { asm volatile("" ::"v"(ya), "v"(yb), "v"(t.t00), "v"(t.za), "v"(t.ch.s1x)); continue; }
-        // ---- phase 1: every lane walks the spans of its own (small) triangle ----------------
-        if (have && !big) {
-            for (int y = ya; y <= yb; y++) {
-                int lo, hi;
-                row_span(t.ch, y, lo, hi);
-                lo = max(lo, X0);
-                hi = min(hi, X1);
-                const float dy = ((float)y + 0.5f) - t.cfy;
-                const float r0 = t.t01 * dy, r1 = t.t11 * dy;
-                const int rowbase = (y - Y0) * TILE_W - X0;
-                if (a.variant == 2) { asm volatile("" ::"v"(lo), "v"(hi), "v"(r0), "v"(r1)); continue; }
-                for (int x = lo; x <= hi; x++) fragment<ZTEST>(keys, t, x, rowbase + x, r0, r1, a.variant);
+        // ---- phase 1: lane = triangle for the row walk, lane = fragment for the pixel work ----
+        // Every lane steps through the rows of ITS OWN (small) triangle; per row step the span
+        // widths are prefix-summed across the wave and the fragments of all 64 spans are dealt
+        // out densely, one per lane: the owner lane of fragment j is found with a start-marker
+        // scatter + max-scan, its row constants are pulled with ds_bpermute.
+        {
+            const bool mine = have && !big;
+            int y = mine ? ya : 1;
+            const int ye = mine ? yb : 0;
+            volatile uint32_t* mk = span_mark[tid >> 6];
+            while (VAR != 4 && __any(y <= ye)) {
+                const bool act = y <= ye;
+                int lo = 0, hi = -1;
+                float r0 = 0.0f, r1 = 0.0f;
+                if (act) {
+                    row_span_small(t.ch, y, lo, hi);
+                    lo = max(lo, X0);
+                    hi = min(hi, X1);
+                    const float dy = ((float)y + 0.5f) - t.cfy;
+                    r0 = t.t01 * dy;
+                    r1 = t.t11 * dy;
+                }
+                const int w = act ? max(hi - lo + 1, 0) : 0;
+                const int pin = wave_incl_add(w);
+                const int pex = pin - w;
+                const int T = __builtin_amdgcn_readlane(pin, 63);
+                // fragment j of this row step: tile-local key index = L + j, dx = float(D + j)
+                // (small coordinates: (x + .5) - (cx + .5) == x - cx exactly, |x|,|cx| < 2^22)
+                const int L = (y - Y0) * TILE_W + (lo - X0) - pex;      // 13 bits signed
+                // NOTE: fragment index j below is relative to the row step (0..T)
+                const int D = lo - t.cx - pex;                          // 17 bits signed
+                const int packed = (int)(((uint32_t)D << 13) | ((uint32_t)L & 0x1FFFu));
+                if (VAR == 3) asm volatile("" ::"v"(packed), "v"(r0), "v"(r1));
+                // Owner search for up to SUPER dense steps at once: ONE tagged marker scatter
+                // (stale markers carry an older tag, so the array is never re-zeroed), then
+                // independent reads + max-scans per step (their latencies overlap).
+                int carry = 0;
+                for (int sbase = 0; VAR != 3 && sbase < T; sbase += 64 * SUPER) {
+                    tag++;
+                    const int s0 = pex - sbase;
+                    if (w > 0 && s0 >= 0 && s0 < 64 * SUPER) mk[s0] = ((uint32_t)tag << 7) | (uint32_t)(lane + 1);
+                    int own1[SUPER];
+#pragma unroll
+                    for (int k = 0; k < SUPER; k++) {
+                        const uint32_t v = mk[64 * k + lane];
+                        own1[k] = wave_incl_max((v >> 7) == (uint32_t)tag ? (int)(v & 127u) : 0);
+                    }
+#pragma unroll
+                    for (int k = 0; k < SUPER; k++) {
+                        own1[k] = max(own1[k], carry);     // span continuing from the previous step
+                        carry = __builtin_amdgcn_readlane(own1[k], 63);
+                    }
+#pragma unroll
+                    for (int k = 0; k < SUPER; k++) {
+                        const int base = sbase + 64 * k;
+                        if (base >= T) break;
+                        const int src = (own1[k] - 1) << 2;
+                        const int j = base + lane;
+                        if (VAR == 2) { asm volatile("" ::"v"(src)); continue; }
+                        const int pk = pull_i(src, packed);
+                        const uint32_t oprim = (uint32_t)pull_i(src, (int)t.prim);
+                        const int lidx = ((int)((uint32_t)pk << 19) >> 19) + j;
+                        unsigned long long key;
+                        bool live = j < T;
+                        if (ZTEST) {
+                            const float o00 = pull_f(src, t.t00), o10 = pull_f(src, t.t10);
+                            const float or0 = pull_f(src, r0), or1 = pull_f(src, r1);
+                            const float oza = VAR == 6 ? t.za : pull_f(src, t.za), ozb = VAR == 6 ? t.zb : pull_f(src, t.zb),
+                                        ozc = VAR == 6 ? t.zc : pull_f(src, t.zc);
+                            if (VAR == 5) {
+                                asm volatile("" ::"v"(o00), "v"(o10), "v"(or0), "v"(or1), "v"(oza), "v"(ozb), "v"(ozc), "v"(pk), "v"(oprim));
+                                continue;
+                            }
+                            const float dx = (float)((pk >> 13) + j);
+                            const float w0 = o00 * dx + or0;
+                            const float w1 = o10 * dx + or1;
+                            const float w2 = 1.0f - w0 - w1;
+                            float d = oza * w0 + ozb * w1 + ozc * w2;
+                            live = live && (d < INFINITY);
+                            d = d + 0.0f;
+                            key = ((unsigned long long)orderable_depth(d) << 32) | (unsigned long long)oprim;
+                        } else {
+                            key = (unsigned long long)(0xFFFFFFFFu - oprim);
+                        }
+                        if (VAR == 1) { asm volatile("" ::"v"((uint32_t)key), "v"((uint32_t)(key >> 32)), "v"(lidx), "v"(live)); continue; }
+                        if (live) atomicMin(&keys[lidx], key);
+                    }
+                }
+                y++;
             }
         }
 
@@ -556,7 +740,8 @@ __global__ __launch_bounds__(RASTER_THREADS) void k_raster(RasterArgs a) {
             }
         }
     }
-    __syncthreads();
+    __syncthreads();   // sorted[] is rewritten by the next segment
+    }
 
     // ---- resolve: key -> pixel, one coalesced write per pixel --------------------------------
     const bool want_color = a.color != nullptr;
@@ -698,11 +883,11 @@ void launch_fill(const DeviceFrame& f, hipStream_t s) {
     if (f.plan.use_lds) {
         hipLaunchKernelGGL(k_fill_lds, dim3(f.plan.G), dim3(1024), f.plan.lds_bytes, s, f.ranges, f.ntri,
                            f.bin_matrix, f.tile_start, f.counters, f.bins, f.capacity, f.plan.chunk, ntiles,
-                           f.tg.tiles_x);
+                           f.tg.tiles_x, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
     } else {
         const unsigned blocks = (unsigned)((f.ntri + 255) / 256);
         hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, s, f.ranges, f.ntri, f.tile_cursor, f.counters,
-                           f.bins, f.capacity, f.tg.tiles_x);
+                           f.bins, f.capacity, f.tg.tiles_x, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
     }
 }
 
@@ -712,11 +897,23 @@ void launch_raster(const DeviceFrame& f, hipStream_t s) {
     a.counters = f.counters; a.capacity = f.capacity;
     a.color = (f.flags & SWR_FLAG_NO_COLOR) ? nullptr : f.color;
     a.depth = f.depth; a.tg = f.tg;
-    static const int variant = getenv("SWR_DEBUG_VARIANT") ? atoi(getenv("SWR_DEBUG_VARIANT")) : 0;
-    a.variant = variant;
+    a.tag_class = f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0;
     const unsigned tiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
     if (tiles == 0) return;
-    if (f.flags & SWR_FLAG_DEPTH_TEST)
+    static const int variant = getenv("SWR_DEBUG_VARIANT") ? atoi(getenv("SWR_DEBUG_VARIANT")) : 0;
+    if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 1)
+        hipLaunchKernelGGL((k_raster<true, 1>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 2)
+        hipLaunchKernelGGL((k_raster<true, 2>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 3)
+        hipLaunchKernelGGL((k_raster<true, 3>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 4)
+        hipLaunchKernelGGL((k_raster<true, 4>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 5)
+        hipLaunchKernelGGL((k_raster<true, 5>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 6)
+        hipLaunchKernelGGL((k_raster<true, 6>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+    else if (f.flags & SWR_FLAG_DEPTH_TEST)
         hipLaunchKernelGGL(k_raster<true>, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
     else
         hipLaunchKernelGGL(k_raster<false>, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);

@@ -1,0 +1,49 @@
+// GpuRenderer.swift — drop-in replacement body for renderer/GpuRenderer.swift:12-147.
+// Same class name, same `render(renderPass:)` signature (GpuRenderer.swift:35), same RenderPass /
+// Image / Vertex / Pixel types (they stay in the app's Renderer.swift:5-200 untouched).  Where the
+// original builds MTLBuffers, encodes vertex_pass / roi_pass and one rasterizer_pass dispatch per
+// triangle and blocks twice in scheduleAndWait, this forwards the pass to libswr_hip.so.
+//
+// NOT COMPILED IN THIS REPOSITORY'S IMAGE (no Swift toolchain; the app also imports Apple-only
+// simd/Metal).  On a Linux host with Swift: swiftc -I <this dir> -L <lib dir> -lswr_hip ...
+import CSwr
+
+final class GpuRenderer {
+    private var ctx: OpaquePointer?
+    /// The Metal path z-tests (Shaders.metal:158-165); false reproduces Renderer.swift as written.
+    var depthTest = true
+
+    init() {
+        var cfg = swr_config(device: -1, reserved: 0)
+        let rc = swr_context_create(&cfg, &ctx)
+        precondition(rc == SWR_OK, String(cString: swr_last_error(nil)))   // original: try! (GpuRenderer.swift:20-31)
+    }
+
+    deinit { swr_context_destroy(ctx) }
+
+    func render(renderPass: RenderPass) {
+        var pass = swr_render_pass()
+        pass.color = UnsafeMutableRawPointer(renderPass.colorBuffer.pointer)
+        pass.depth = renderPass.depthBuffer.pointer
+        pass.width = Int64(renderPass.colorBuffer.width)
+        pass.height = Int64(renderPass.colorBuffer.height)
+        pass.color_bytes_per_row = Int64(renderPass.colorBuffer.bytesPerRow)
+        pass.depth_bytes_per_row = Int64(renderPass.depthBuffer.bytesPerRow)
+        pass.primitive_type = renderPass.primitiveType == .triangle ? 0 : (renderPass.primitiveType == .line ? 1 : 2)
+        pass.flags = depthTest ? UInt32(SWR_FLAG_DEPTH_TEST) : 0
+        withUnsafeBytes(of: renderPass.transform) { src in          // matrix_float4x4 = 4 float4 columns
+            withUnsafeMutableBytes(of: &pass.transform) { $0.copyMemory(from: src) }
+        }
+        // Vertex is two SIMD3<Float> = 32 bytes, the layout of swr_vertex (Renderer.swift:154-157)
+        renderPass.vertices.withUnsafeBytes { v in
+            renderPass.indices.withUnsafeBufferPointer { i in
+                pass.vertices = v.baseAddress?.assumingMemoryBound(to: swr_vertex.self)
+                pass.vertex_count = Int64(renderPass.vertices.count)
+                i.baseAddress!.withMemoryRebound(to: Int64.self, capacity: i.count) { pass.indices = $0 }
+                pass.index_count = Int64(i.count)
+                let rc = swr_render(ctx, &pass)
+                precondition(rc == SWR_OK, String(cString: swr_last_error(ctx)))
+            }
+        }
+    }
+}

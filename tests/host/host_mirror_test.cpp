@@ -1,0 +1,75 @@
+// Exercises the C++ mirror of the reference's host interface (software-renderer_amd/host/Renderer.hpp)
+// the way App.swift:153-185 drives the reference: build a RenderPass, call renderer.render(pass).
+// Checks the SURVEY.md §C.1 known answer and the z-test / painter's-order difference.
+// Exit code 0 = pass.  Needs a HIP device (no CPU fallback).
+#include <cmath>
+#include <cstdio>
+#include <vector>
+
+#include "../../software-renderer_amd/host/Renderer.hpp"
+
+using namespace swr_host;
+
+static int fails = 0;
+#define CHECK(c) do { if (!(c)) { std::printf("FAIL %s:%d %s\n", __FILE__, __LINE__, #c); fails++; } } while (0)
+
+int main() {
+    const long W = 256, H = 256;
+    std::vector<Pixel> color(W * H, Pixel{9, 9, 9, 9});
+    std::vector<float> depth(W * H, -1.0f);
+    try {
+        GpuRenderer gpuRenderer;            // App.swift:149
+        Renderer renderer;                  // App.swift:148
+        RenderPass pass{ColorImage(color.data(), W, H, W * 4), DepthImage(depth.data(), W, H, W * 4),
+                        {Vertex(0.0f, 0.5f, 0.5f, 1.0f, 0.5f, 0.25f), Vertex(0.5f, -0.5f, 0.5f, 1.0f, 0.5f, 0.25f),
+                         Vertex(-0.5f, -0.5f, 0.5f, 1.0f, 0.5f, 0.25f)},
+                        {0, 1, 2}};
+        pass.primitiveType = PrimitiveType::triangle;
+        renderer.render(pass);              // as-written CPU semantics
+        long covered = 0;
+        for (long i = 0; i < W * H; i++) {
+            if (color[i].a == 255) {
+                covered++;
+                CHECK(color[i].b == 63 && color[i].g == 127 && color[i].r == 255);
+            } else {
+                CHECK(color[i].b == 0 && color[i].g == 0 && color[i].r == 0 && color[i].a == 0);
+            }
+            CHECK(std::isinf(depth[i]) && depth[i] > 0);
+        }
+        CHECK(covered == 8193);
+        CHECK(pass.colorBuffer.at(64, 192).a == 255 && pass.colorBuffer.at(65, 192).a == 0);   // flat-bottom quirk
+
+        // two coplanar-in-xy triangles at different depth: painter's order vs z-test
+        pass.vertices = {Vertex(0, .8f, .2f, 1, 0, 0), Vertex(.8f, -.8f, .2f, 1, 0, 0), Vertex(-.8f, -.8f, .2f, 1, 0, 0),
+                         Vertex(0, .8f, .7f, 0, 0, 1), Vertex(.8f, -.8f, .7f, 0, 0, 1), Vertex(-.8f, -.8f, .7f, 0, 0, 1)};
+        pass.indices = {0, 1, 2, 3, 4, 5};
+        renderer.render(pass);
+        CHECK(pass.colorBuffer.at(128, 128).b == 255 && pass.colorBuffer.at(128, 128).r == 0);   // last drawn wins
+        gpuRenderer.render(pass);
+        CHECK(pass.colorBuffer.at(128, 128).r == 255 && pass.colorBuffer.at(128, 128).b == 0);   // nearest wins
+        CHECK(pass.depthBuffer.at(128, 128) == 0.2f);
+
+        // transform path: matrix_float4x4(rows:) * identity, as App.swift:176-183
+        const float rows[4][4] = {{1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 1, 1}};
+        pass.transform = matrix_float4x4::fromRows(rows) * matrix_float4x4::identity();
+        gpuRenderer.render(pass);           // w = z + 1: shrinks towards the centre
+        CHECK(pass.colorBuffer.at(128, 128).a == 255);
+        CHECK(pass.colorBuffer.at(128, 40).a == 0);
+
+        // the reference traps on a bad index (Renderer.swift:226); the mirror throws
+        pass.indices = {0, 1, 99};
+        bool threw = false;
+        try { gpuRenderer.render(pass); } catch (const RenderError& e) { threw = e.code == SWR_ERR_INDEX_RANGE; }
+        CHECK(threw);
+        pass.primitiveType = PrimitiveType::line;   // stub in the reference (Renderer.swift:289-293)
+        pass.indices = {0, 1, 2};
+        threw = false;
+        try { gpuRenderer.render(pass); } catch (const RenderError& e) { threw = e.code == SWR_ERR_UNSUPPORTED; }
+        CHECK(threw);
+    } catch (const RenderError& e) {
+        std::printf("RenderError %d: %s\n", e.code, e.what());
+        return 2;
+    }
+    std::printf(fails ? "host mirror: %d failures\n" : "host mirror: ok\n", fails);
+    return fails ? 1 : 0;
+}

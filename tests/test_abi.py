@@ -90,3 +90,16 @@ def test_product_package_never_imports_the_oracle():
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "swr_oracle" not in text and "swro_" not in text, f
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+
+
+def test_host_mirror_compiles_against_the_c_abi(swr):
+    """software-renderer_amd/host/Renderer.hpp (C++ mirror of Renderer / GpuRenderer / RenderPass)
+    builds with plain g++ against include/swr.h + the shared library — no HIP headers needed."""
+    swr.build()
+    subprocess.check_call(["make", "-C", os.path.join(ROOT, "software-renderer_amd"), "-s", "lib/host_mirror_test"])
+    exe = os.path.join(ROOT, "software-renderer_amd", "lib", "host_mirror_test")
+    assert os.access(exe, os.X_OK)
+    hdr = open(os.path.join(ROOT, "software-renderer_amd", "host", "Renderer.hpp")).read()
+    for name in ("class Renderer", "class GpuRenderer", "struct RenderPass", "struct Vertex", "struct Pixel",
+                 "enum class PrimitiveType", "class Image", "void render(const RenderPass& renderPass)"):
+        assert name in hdr

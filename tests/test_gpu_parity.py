@@ -313,3 +313,15 @@ def test_global_atomic_binning_fallback(swr, oracle, monkeypatch):
         s = swr.scenes.random_soup(5000, 900, 500, 123, r_ndc=0.05, flags=flags, margin=1.1)
         with swr.Context() as ctx:
             check(ctx, oracle, s)
+
+
+def test_host_mirror_cpp_program(swr):
+    """The C++ mirror of the reference's host interface, driven like App.swift:153-185."""
+    import os
+    import subprocess
+    swr.build()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call(["make", "-C", os.path.join(root, "software-renderer_amd"), "-s", "lib/host_mirror_test"])
+    out = subprocess.run([os.path.join(root, "software-renderer_amd", "lib", "host_mirror_test")],
+                         capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0 and "host mirror: ok" in out.stdout, out.stdout + out.stderr

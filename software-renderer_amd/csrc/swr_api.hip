@@ -177,6 +177,7 @@ int enqueue_frame(swr_context* c) {
     launch_scan(f, c->stream);
     if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     launch_fill(f, c->stream);
+    launch_sort_bins(f, c->stream);
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     launch_raster(f, c->stream);
     if (ev) HIP_TRY(c, hipEventRecord(ev[4], c->stream));

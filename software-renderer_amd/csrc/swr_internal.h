@@ -86,6 +86,7 @@ void launch_validate_indices(const int64_t* indices, int64_t count, int64_t vert
 void launch_setup_bin(const DeviceFrame& f, hipStream_t s);
 void launch_scan(const DeviceFrame& f, hipStream_t s);
 void launch_fill(const DeviceFrame& f, hipStream_t s);
+void launch_sort_bins(const DeviceFrame& f, hipStream_t s);
 void launch_raster(const DeviceFrame& f, hipStream_t s);
 
 }  // namespace swr

@@ -402,6 +402,57 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ coun
 }
 
 // ------------------------------------------------------------------------------------------
+// k_sort_bins: per tile, counting sort of the bin by the 6-bit size class k_fill attached to
+// every entry (heaviest class first), in place, class bits stripped.  After it the 64 triangles
+// a raster wave walks together have the same number of rows inside the tile.  Bins longer than
+// SORT_CAP are sorted in independent segments (still correct: order never affects the image).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int wave_incl_add(int v);
+constexpr int SORT_THREADS = 256;
+constexpr int SORT_CAP = 4 * SORT_THREADS;
+__global__ __launch_bounds__(SORT_THREADS) void k_sort_bins(uint32_t* __restrict__ bins,
+                                                            const uint32_t* __restrict__ tile_start,
+                                                            const uint32_t* __restrict__ counters,
+                                                            uint32_t capacity, int tag_class) {
+    __shared__ uint32_t cls_cnt[64];
+    if (counters[CNT_PAIRS] > capacity) return;
+    const int tid = threadIdx.x;
+    const uint32_t b0 = tile_start[blockIdx.x], b1 = tile_start[blockIdx.x + 1];
+    for (uint32_t seg = b0; seg < b1; seg += SORT_CAP) {
+        const uint32_t m = min((uint32_t)SORT_CAP, b1 - seg);
+        if (tid < 64) cls_cnt[tid] = 0u;
+        __syncthreads();
+        uint32_t ent[SORT_CAP / SORT_THREADS], pos[SORT_CAP / SORT_THREADS];
+#pragma unroll
+        for (int k = 0; k < SORT_CAP / SORT_THREADS; k++) {
+            const uint32_t i = tid + k * SORT_THREADS;
+            ent[k] = 0u; pos[k] = 0u;
+            if (i < m) {
+                ent[k] = bins[seg + i];
+                pos[k] = atomicAdd(&cls_cnt[tag_class ? ent[k] >> CLASS_SHIFT : 0u], 1u);
+            }
+        }
+        __syncthreads();
+        if (tid < 64) {   // wave 0: exclusive prefix over the classes in descending order
+            const int c = NUM_CLASSES - 1 - tid;
+            const uint32_t v = c >= 0 ? cls_cnt[c] : 0u;
+            const uint32_t incl = (uint32_t)wave_incl_add((int)v);
+            if (c >= 0) cls_cnt[c] = incl - v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < SORT_CAP / SORT_THREADS; k++) {
+            const uint32_t i = tid + k * SORT_THREADS;
+            if (i < m) {
+                const uint32_t c = tag_class ? ent[k] >> CLASS_SHIFT : 0u;
+                bins[seg + cls_cnt[c] + pos[k]] = tag_class ? ent[k] & ((1u << CLASS_SHIFT) - 1u) : ent[k];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // k_raster
 // ------------------------------------------------------------------------------------------
 struct RasterArgs {
@@ -491,23 +542,37 @@ template <int CTRL, int ROWMASK>
 __device__ __forceinline__ int dpp0(int v) {
     return __builtin_amdgcn_update_dpp(0, v, CTRL, ROWMASK, 0xF, false);   // lanes without a source get 0
 }
+// One instruction per scan step: OP vdst, dpp(src0), src1 with vdst = src0 = src1; lanes whose DPP
+// source is invalid or whose row is masked off keep their value (bound_ctrl off).  s_nop 1 covers
+// the VALU-write -> DPP-read hazard (2 wait states), which hipcc cannot see inside the asm.
+#define SWR_DPP_SCAN(OP, v)                                                                    \
+    asm volatile("s_nop 1\n\t" OP " %0, %0, %0 row_shr:1 row_mask:0xf bank_mask:0xf\n\t"      \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_shr:2 row_mask:0xf bank_mask:0xf\n\t"      \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_shr:4 row_mask:0xf bank_mask:0xf\n\t"      \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_shr:8 row_mask:0xf bank_mask:0xf\n\t"      \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\t"   \
+                 "s_nop 1\n\t" OP " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\t"   \
+                 "s_nop 1"                                                                     \
+                 : "+v"(v))
 __device__ __forceinline__ int wave_incl_add(int v) {
-    v += dpp0<0x111, 0xF>(v);   // row_shr:1
-    v += dpp0<0x112, 0xF>(v);   // row_shr:2
-    v += dpp0<0x114, 0xF>(v);   // row_shr:4
-    v += dpp0<0x118, 0xF>(v);   // row_shr:8   -> inclusive scan inside each row of 16
-    v += dpp0<0x142, 0xA>(v);   // row_bcast:15 into rows 1,3
-    v += dpp0<0x143, 0xC>(v);   // row_bcast:31 into rows 2,3
+    SWR_DPP_SCAN("v_add_u32_dpp", v);
     return v;
 }
 __device__ __forceinline__ int wave_incl_max(int v) {   // v >= 0
-    v = max(v, dpp0<0x111, 0xF>(v));
-    v = max(v, dpp0<0x112, 0xF>(v));
-    v = max(v, dpp0<0x114, 0xF>(v));
-    v = max(v, dpp0<0x118, 0xF>(v));
-    v = max(v, dpp0<0x142, 0xA>(v));
-    v = max(v, dpp0<0x143, 0xC>(v));
+    SWR_DPP_SCAN("v_max_i32_dpp", v);
     return v;
+}
+// two independent max-scans interleaved: each fills the other's DPP hazard slots
+__device__ __forceinline__ void wave_incl_max2(int& a, int& b) {
+#define SWR_MAX2(CTRL)                                                     \
+    "v_max_i32_dpp %0, %0, %0 " CTRL " bank_mask:0xf\n\t"                  \
+    "v_max_i32_dpp %1, %1, %1 " CTRL " bank_mask:0xf\n\t"                  \
+    "s_nop 0\n\t"
+    asm volatile("s_nop 1\n\t" SWR_MAX2("row_shr:1 row_mask:0xf") SWR_MAX2("row_shr:2 row_mask:0xf")
+                 SWR_MAX2("row_shr:4 row_mask:0xf") SWR_MAX2("row_shr:8 row_mask:0xf")
+                 SWR_MAX2("row_bcast:15 row_mask:0xa") SWR_MAX2("row_bcast:31 row_mask:0xc") "s_nop 0"
+                 : "+v"(a), "+v"(b));
+#undef SWR_MAX2
 }
 __device__ __forceinline__ int pull_i(int byte_addr, int v) { return __builtin_amdgcn_ds_bpermute(byte_addr, v); }
 __device__ __forceinline__ float pull_f(int byte_addr, float v) {
@@ -517,11 +582,11 @@ __device__ __forceinline__ float pull_f(int byte_addr, float v) {
 // VAR > 0: timing-only ablations selected with SWR_DEBUG_VARIANT (results invalid):
 //   1 = no LDS atomic, 2 = no pulls/maths/atomic, 3 = no dense loop, 4 = no row walk at all
 template <bool ZTEST, int VAR = 0>
-__global__ __launch_bounds__(RASTER_THREADS) void k_raster(RasterArgs a) {
+__global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
     constexpr int SUPER = 2;   // dense steps whose owner search is done together
-    constexpr int SORT_CAP = 4 * RASTER_THREADS;   // bin entries sorted per pass
-    __shared__ uint32_t sorted[SORT_CAP];
-    __shared__ uint32_t cls_cnt[NUM_CLASSES + 1];
+    constexpr int UNIT = 4;    // consecutive pixels of one span handled by one lane of a dense step
+    __shared__ float4 tabA[RASTER_THREADS];   // per triangle of the batch: t00, t01, t10, t11
+    __shared__ float4 tabB[RASTER_THREADS];   //                            za, zb, zc, cf.y
     __shared__ uint32_t span_mark[RASTER_THREADS / 64][64 * SUPER];
     __shared__ unsigned long long keys[TILE_W * TILE_H];
 
@@ -544,146 +609,124 @@ __global__ __launch_bounds__(RASTER_THREADS) void k_raster(RasterArgs a) {
     const uint32_t b0 = overflow ? 0u : a.tile_start[tile];
     const uint32_t b1 = overflow ? 0u : a.tile_start[tile + 1];
 
-    const uint32_t n_all = b1 - b0;
-    for (uint32_t seg = 0; seg < n_all; seg += SORT_CAP) {
-    const uint32_t m = min((uint32_t)SORT_CAP, n_all - seg);
-    // ---- counting sort of (this segment of) the bin by size class, heaviest class first -------
-    // so that the 64 triangles a wave walks together have the same number of rows in the tile
-    if (tid <= NUM_CLASSES) cls_cnt[tid] = 0u;
-    __syncthreads();
-    {
-        uint32_t ent[SORT_CAP / RASTER_THREADS], pos[SORT_CAP / RASTER_THREADS];
-#pragma unroll
-        for (int k = 0; k < SORT_CAP / RASTER_THREADS; k++) {
-            const uint32_t i = tid + k * RASTER_THREADS;
-            ent[k] = 0u; pos[k] = 0u;
-            if (i < m) {
-                ent[k] = a.bins[b0 + seg + i];
-                pos[k] = atomicAdd(&cls_cnt[a.tag_class ? ent[k] >> CLASS_SHIFT : 0u], 1u);
-            }
-        }
-        __syncthreads();
-        if (tid < 64) {   // wave 0: exclusive prefix over the classes in descending order
-            const int c = NUM_CLASSES - 1 - tid;
-            const uint32_t v = c >= 0 ? cls_cnt[c] : 0u;
-            const uint32_t incl = (uint32_t)wave_incl_add((int)v);
-            if (c >= 0) cls_cnt[c] = incl - v;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int k = 0; k < SORT_CAP / RASTER_THREADS; k++) {
-            const uint32_t i = tid + k * RASTER_THREADS;
-            if (i < m) {
-                const uint32_t c = a.tag_class ? ent[k] >> CLASS_SHIFT : 0u;
-                sorted[cls_cnt[c] + pos[k]] = a.tag_class ? ent[k] & ((1u << CLASS_SHIFT) - 1u) : ent[k];
-            }
-        }
-        __syncthreads();
-    }
-    for (uint32_t base = 0; base < m; base += RASTER_THREADS) {
-        const uint32_t e = base + tid;
+    const uint32_t m = b1 - b0;   // bin already sorted by size class (k_sort_bins), heaviest first
+    for (uint32_t base0 = 0; VAR != 9 && VAR != 11 && base0 < m; base0 += RASTER_THREADS) {
+        const uint32_t e = base0 + tid;
         const bool have = e < m;
         TriState t;
         int ya = 1, yb = 0, bxa = 0, bxb = -1;
         bool big = false;
         if (have) {
             int minx, maxx;
-            load_tri(a.geo, sorted[e], t, minx, maxx);
+            load_tri(a.geo, a.bins[b0 + e], t, minx, maxx);
             ya = max(t.ch.s0y, Y0);
             yb = min(t.ch.s2y, Y1);
             bxa = max(minx, X0);
             bxb = min(maxx, X1);
             // the dense path below needs the exact small-coordinate arithmetic; everything else
             // (huge extents, large clipped area) is walked cooperatively in phase 2
-            big = !t.ch.small || (yb - ya + 1) * (bxb - bxa + 1) > BIG_AREA;
+            big = !t.ch.small || maxx - minx >= 16384 || (yb - ya + 1) * (bxb - bxa + 1) > BIG_AREA;
         }
 
-        // ---- phase 1: lane = triangle for the row walk, lane = fragment for the pixel work ----
-        // Every lane steps through the rows of ITS OWN (small) triangle; per row step the span
-        // widths are prefix-summed across the wave and the fragments of all 64 spans are dealt
-        // out densely, one per lane: the owner lane of fragment j is found with a start-marker
-        // scatter + max-scan, its row constants are pulled with ds_bpermute.
+        // ---- phase 1: lane = triangle for the row walk, lane = 4-pixel unit for the pixel work --
+        // Every lane steps through the rows of ITS OWN (small) triangle.  Per row step each span is
+        // cut into units of UNIT consecutive pixels; the unit counts are prefix-summed across the
+        // wave and the units of all 64 spans are dealt out densely, one per lane.  The owner lane
+        // and the first unit of its span reach unit j through a start-marker scatter + max-scan;
+        // the owner's per-row word comes by ds_bpermute, its per-triangle constants from a small
+        // LDS table (2 x ds_read_b128); the UNIT pixels are then evaluated with packed f32 maths.
         {
             const bool mine = have && !big;
+            const int wbase = tid & ~63;
+            if (ZTEST) {   // same-wave producers and consumers: LDS ops of a wave execute in order
+                tabA[tid] = make_float4(t.t00, t.t01, t.t10, t.t11);
+                tabB[tid] = make_float4(t.za, t.zb, t.zc, t.cfy);
+            }
             int y = mine ? ya : 1;
             const int ye = mine ? yb : 0;
             volatile uint32_t* mk = span_mark[tid >> 6];
-            while (VAR != 4 && __any(y <= ye)) {
+            while (VAR != 4 && VAR != 10 && __any(y <= ye)) {
                 const bool act = y <= ye;
                 int lo = 0, hi = -1;
-                float r0 = 0.0f, r1 = 0.0f;
                 if (act) {
                     row_span_small(t.ch, y, lo, hi);
                     lo = max(lo, X0);
                     hi = min(hi, X1);
-                    const float dy = ((float)y + 0.5f) - t.cfy;
-                    r0 = t.t01 * dy;
-                    r1 = t.t11 * dy;
                 }
                 const int w = act ? max(hi - lo + 1, 0) : 0;
-                const int pin = wave_incl_add(w);
-                const int pex = pin - w;
-                const int T = __builtin_amdgcn_readlane(pin, 63);
-                // fragment j of this row step: tile-local key index = L + j, dx = float(D + j)
-                // (small coordinates: (x + .5) - (cx + .5) == x - cx exactly, |x|,|cx| < 2^22)
-                const int L = (y - Y0) * TILE_W + (lo - X0) - pex;      // 13 bits signed
-                // NOTE: fragment index j below is relative to the row step (0..T)
-                const int D = lo - t.cx - pex;                          // 17 bits signed
-                const int packed = (int)(((uint32_t)D << 13) | ((uint32_t)L & 0x1FFFu));
-                if (VAR == 3) asm volatile("" ::"v"(packed), "v"(r0), "v"(r1));
-                // Owner search for up to SUPER dense steps at once: ONE tagged marker scatter
-                // (stale markers carry an older tag, so the array is never re-zeroed), then
-                // independent reads + max-scans per step (their latencies overlap).
+                const int nu = (w + UNIT - 1) / UNIT;              // units of this span
+                const int pin = wave_incl_add(nu);
+                const int pex = pin - nu;
+                const int T = __builtin_amdgcn_readlane(pin, 63);   // units of this row step
+                // per-row word of the owner: tile-local row (5 bits), span start and end (6 + 6 bits),
+                // lo - C.x (15 bits signed; small coordinates: (x+.5) - (cx+.5) == x - cx exactly)
+                const int packed = ((y - Y0) & 31) | (((lo - X0) & 63) << 5) | (((hi - X0) & 63) << 11) |
+                                   ((lo - t.cx) << 17);
+                if (VAR == 3) asm volatile("" ::"v"(packed));
+                // Owner search for SUPER dense steps at once: ONE tagged marker scatter (stale
+                // markers carry an older tag, so the strip is never re-zeroed), then the reads and
+                // two interleaved max-scans.  The scanned value is (first unit + 1) << 7 |
+                // (owner lane + 1); it is monotone in the slot.
                 int carry = 0;
                 for (int sbase = 0; VAR != 3 && sbase < T; sbase += 64 * SUPER) {
                     tag++;
                     const int s0 = pex - sbase;
-                    if (w > 0 && s0 >= 0 && s0 < 64 * SUPER) mk[s0] = ((uint32_t)tag << 7) | (uint32_t)(lane + 1);
-                    int own1[SUPER];
+                    if (nu > 0 && s0 >= 0 && s0 < 64 * SUPER) mk[s0] = ((uint32_t)tag << 7) | (uint32_t)(lane + 1);
+                    int own[SUPER];
 #pragma unroll
                     for (int k = 0; k < SUPER; k++) {
                         const uint32_t v = mk[64 * k + lane];
-                        own1[k] = wave_incl_max((v >> 7) == (uint32_t)tag ? (int)(v & 127u) : 0);
+                        const int start1 = sbase + 64 * k + lane + 1;
+                        own[k] = (v >> 7) == (uint32_t)tag ? (int)((start1 << 7) | (int)(v & 127u)) : 0;
                     }
+                    static_assert(SUPER == 2, "the interleaved scan handles two steps");
+                    wave_incl_max2(own[0], own[1]);
 #pragma unroll
                     for (int k = 0; k < SUPER; k++) {
-                        own1[k] = max(own1[k], carry);     // span continuing from the previous step
-                        carry = __builtin_amdgcn_readlane(own1[k], 63);
+                        own[k] = max(own[k], carry);     // span continuing from the previous step
+                        carry = __builtin_amdgcn_readlane(own[k], 63);
                     }
 #pragma unroll
                     for (int k = 0; k < SUPER; k++) {
                         const int base = sbase + 64 * k;
                         if (base >= T) break;
-                        const int src = (own1[k] - 1) << 2;
+                        const int owner = (own[k] & 127) - 1;
                         const int j = base + lane;
-                        if (VAR == 2) { asm volatile("" ::"v"(src)); continue; }
-                        const int pk = pull_i(src, packed);
-                        const uint32_t oprim = (uint32_t)pull_i(src, (int)t.prim);
-                        const int lidx = ((int)((uint32_t)pk << 19) >> 19) + j;
-                        unsigned long long key;
-                        bool live = j < T;
+                        const int offu = j - ((own[k] >> 7) - 1);    // unit index inside the owner's span
+                        if (VAR == 2) { asm volatile("" ::"v"(owner), "v"(offu)); continue; }
+                        const int pk = pull_i(owner << 2, packed);
+                        const uint32_t oprim = (uint32_t)pull_i(owner << 2, (int)t.prim);
+                        float4 ta = make_float4(0, 0, 0, 0), tb = make_float4(0, 0, 0, 0);
+                        if (ZTEST) { ta = tabA[wbase + owner]; tb = tabB[wbase + owner]; }
+                        const int yl = pk & 31;
+                        const int xl0 = ((pk >> 5) & 63) + UNIT * offu;          // first pixel of the unit
+                        const int nvalid = j < T ? ((pk >> 11) & 63) - xl0 + 1 : 0;   // pixels left in the span
+                        const int lidx0 = yl * TILE_W + xl0;
+                        if (VAR == 5) { asm volatile("" ::"v"(ta.x), "v"(ta.y), "v"(ta.z), "v"(ta.w), "v"(tb.x), "v"(tb.y), "v"(tb.z), "v"(tb.w), "v"(nvalid), "v"(lidx0), "v"(oprim)); continue; }
                         if (ZTEST) {
-                            const float o00 = pull_f(src, t.t00), o10 = pull_f(src, t.t10);
-                            const float or0 = pull_f(src, r0), or1 = pull_f(src, r1);
-                            const float oza = VAR == 6 ? t.za : pull_f(src, t.za), ozb = VAR == 6 ? t.zb : pull_f(src, t.zb),
-                                        ozc = VAR == 6 ? t.zc : pull_f(src, t.zc);
-                            if (VAR == 5) {
-                                asm volatile("" ::"v"(o00), "v"(o10), "v"(or0), "v"(or1), "v"(oza), "v"(ozb), "v"(ozc), "v"(pk), "v"(oprim));
-                                continue;
+                            const float dx0 = (float)((pk >> 17) + UNIT * offu);
+                            const float dy = ((float)(Y0 + yl) + 0.5f) - tb.w;   // (y + .5) - cf.y
+                            const float r0 = ta.y * dy, r1 = ta.w * dy;          // t01*dy, t11*dy
+#pragma unroll
+                            for (int q = 0; q < UNIT; q++) {
+                                const float dx = dx0 + (float)q;                 // exact: small integers
+                                const float w0 = ta.x * dx + r0;
+                                const float w1 = ta.z * dx + r1;
+                                const float w2 = 1.0f - w0 - w1;
+                                float d = tb.x * w0 + tb.y * w1 + tb.z * w2;
+                                const bool live = q < nvalid && d < INFINITY;
+                                d = d + 0.0f;
+                                const unsigned long long key =
+                                    ((unsigned long long)orderable_depth(d) << 32) | (unsigned long long)oprim;
+                                if (VAR == 1) { asm volatile("" ::"v"((uint32_t)key), "v"((uint32_t)(key >> 32)), "v"(live)); continue; }
+                                if (live) atomicMin(&keys[lidx0 + q], key);
                             }
-                            const float dx = (float)((pk >> 13) + j);
-                            const float w0 = o00 * dx + or0;
-                            const float w1 = o10 * dx + or1;
-                            const float w2 = 1.0f - w0 - w1;
-                            float d = oza * w0 + ozb * w1 + ozc * w2;
-                            live = live && (d < INFINITY);
-                            d = d + 0.0f;
-                            key = ((unsigned long long)orderable_depth(d) << 32) | (unsigned long long)oprim;
                         } else {
-                            key = (unsigned long long)(0xFFFFFFFFu - oprim);
+                            const unsigned long long key = (unsigned long long)(0xFFFFFFFFu - oprim);
+#pragma unroll
+                            for (int q = 0; q < UNIT; q++)
+                                if (q < nvalid) atomicMin(&keys[lidx0 + q], key);
                         }
-                        if (VAR == 1) { asm volatile("" ::"v"((uint32_t)key), "v"((uint32_t)(key >> 32)), "v"(lidx), "v"(live)); continue; }
-                        if (live) atomicMin(&keys[lidx], key);
                     }
                 }
                 y++;
@@ -740,14 +783,13 @@ __global__ __launch_bounds__(RASTER_THREADS) void k_raster(RasterArgs a) {
             }
         }
     }
-    __syncthreads();   // sorted[] is rewritten by the next segment
-    }
+    __syncthreads();
 
     // ---- resolve: key -> pixel, one coalesced write per pixel --------------------------------
     const bool want_color = a.color != nullptr;
     const int W = a.tg.width;
     const bool vec_ok = (W & 3) == 0;
-    for (int i = tid; i < TILE_W * TILE_H / 4; i += RASTER_THREADS) {
+    for (int i = tid; VAR != 8 && VAR != 10 && VAR != 11 && i < TILE_W * TILE_H / 4; i += RASTER_THREADS) {
         const int ly = (i * 4) / TILE_W, lx = (i * 4) % TILE_W;
         const int y = Y0 + ly, x = X0 + lx;
         if (y > Y1 || x > X1) continue;
@@ -891,6 +933,13 @@ void launch_fill(const DeviceFrame& f, hipStream_t s) {
     }
 }
 
+void launch_sort_bins(const DeviceFrame& f, hipStream_t s) {
+    const unsigned tiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
+    if (f.ntri <= 0 || tiles == 0) return;
+    hipLaunchKernelGGL(k_sort_bins, dim3(tiles), dim3(SORT_THREADS), 0, s, f.bins, f.tile_start, f.counters,
+                       f.capacity, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
+}
+
 void launch_raster(const DeviceFrame& f, hipStream_t s) {
     RasterArgs a;
     a.geo = f.geo; a.col = f.col; a.tile_start = f.tile_start; a.bins = f.bins;
@@ -911,8 +960,14 @@ void launch_raster(const DeviceFrame& f, hipStream_t s) {
         hipLaunchKernelGGL((k_raster<true, 4>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
     else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 5)
         hipLaunchKernelGGL((k_raster<true, 5>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 6)
-        hipLaunchKernelGGL((k_raster<true, 6>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 8)
+        hipLaunchKernelGGL((k_raster<true, 8>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 9)
+        hipLaunchKernelGGL((k_raster<true, 9>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 10)
+        hipLaunchKernelGGL((k_raster<true, 10>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 11)
+        hipLaunchKernelGGL((k_raster<true, 11>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
     else if (f.flags & SWR_FLAG_DEPTH_TEST)
         hipLaunchKernelGGL(k_raster<true>, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
     else

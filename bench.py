@@ -90,11 +90,22 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
+    device = local_rank
+    rehearsal = False
     if world > 1:
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        ndev = torch.cuda.device_count()
+        if ndev >= world or os.environ.get("SWR_BENCH_BACKEND", "") == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            # rehearsal on a box with fewer GPUs than ranks (e.g. 2 ranks on the 1-GPU dev box):
+            # same code path, ranks share devices, gloo carries the barrier / MAX.  Not a result.
+            rehearsal = True
+            device = local_rank % max(ndev, 1)
+            torch.cuda.set_device(device)
+            dist.init_process_group("gloo")
     else:
         try:
             import torch
@@ -113,7 +124,7 @@ def main():
     W, H = scene.width, scene.height
     r0, r1 = shard_rows(swr_amd, H, world, rank)
 
-    ctx = swr_amd.Context(local_rank if world > 1 else -1)
+    ctx = swr_amd.Context(device if world > 1 else -1)
     ctx.scene_upload(scene.vertices, scene.indices)
     ctx.target_set(W, H, r0, r1)
 
@@ -126,11 +137,11 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def timed(flags, steps, warmup):
+    def timed(flags, steps, warmup, level=1):
         for _ in range(warmup):
             ctx.draw(scene.transform, flags)
         sync_all()
-        ctx.timing_enable(True)
+        ctx.timing_enable(level)
         ctx.timing_reset()
         barrier()
         sync_all()
@@ -141,10 +152,10 @@ def main():
         barrier()
         t1 = time.perf_counter()
         sums, frames = ctx.timing_totals()
-        ctx.timing_enable(False)
+        ctx.timing_enable(0)
         dt = t1 - t0
         if dist is not None:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
         return dt, sums, frames
@@ -163,12 +174,15 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": "k_raster<ztest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-        "traffic": (traffic or {}).get("k_raster_bytes_per_launch"),
+        "traffic": (traffic or {}).get("k_raster_bytes_per_launch") if world == 1 else None,
         "algorithmic_bytes_per_launch": band_px * bytes_per_px,
         "avg_launch_ms": round(raster_ms, 5), "launches_timed": frames,
         "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 5),
     }
-    kernels = {k: round(v / max(frames, 1), 5) for k, v in sums.items() if k.endswith("_ms")}
+    # per-stage breakdown from a short separate run with events around every stage (those events
+    # cost stream time, so they stay out of the timed region above)
+    _, sums_all, frames_all = timed(flags, max(args.steps // 10, 5), 2, level=2)
+    kernels = {k: round(v / max(frames_all, 1), 5) for k, v in sums_all.items() if k.endswith("_ms")}
     t_last = ctx.timings()
 
     extra = {"frames_per_s": round(args.steps / dt, 2), "kernel_ms_avg": kernels,
@@ -192,7 +206,8 @@ def main():
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"cfg4: {scene.triangles} random triangles (3 unshared vertices each), {W}x{H}, "
                                f"z-test, {'colour+depth' if args.color else 'depth-only'}, SplitMix64 seed 0x5EED0004",
-                   "sharding": f"{world} tile-row band(s), scene replicated, no collective"},
+                   "sharding": f"{world} tile-row band(s), scene replicated, no collective"
+                               + (" [REHEARSAL: ranks share GPUs, gloo]" if rehearsal else "")},
         "roofline": roofline, "extra": extra,
     }
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -143,8 +143,10 @@ int swr_sync(swr_context* ctx);
 int swr_read_color(swr_context* ctx, void* dst_full_image);
 int swr_read_depth(swr_context* ctx, float* dst_full_image);
 
-/* Timing instrumentation (hipEvents on the context stream around each kernel). */
-int swr_timing_enable(swr_context* ctx, int enable);
+/* Timing instrumentation: hipEvents on the context stream.  level 0 = off, 1 = two events around
+ * the dominant kernel (k_raster) only, 2 = around every stage (each event costs a few us of
+ * stream time, so level 2 perturbs the frame it measures). */
+int swr_timing_enable(swr_context* ctx, int level);
 int swr_get_timings(swr_context* ctx, swr_timings* out);          /* the last frame */
 /* Sums over every frame drawn since swr_timing_reset (events are kept in a ring, so a whole
  * timed region of frames is measured without a host sync per frame). */

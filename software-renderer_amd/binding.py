@@ -189,8 +189,10 @@ class Context:
         self._check(self._L.swr_read_depth(self._h, out.ctypes.data))
         return out
 
-    def timing_enable(self, on: bool = True):
-        self._check(self._L.swr_timing_enable(self._h, 1 if on else 0))
+    def timing_enable(self, level=2):
+        """0/False off, 1 = events around k_raster only, 2/True = around every stage."""
+        level = 2 if level is True else (0 if level is False else int(level))
+        self._check(self._L.swr_timing_enable(self._h, level))
 
     def timings(self) -> dict:
         t = Timings()

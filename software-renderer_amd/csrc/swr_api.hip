@@ -32,7 +32,7 @@ struct swr_context {
     std::string err;
 
     // scene (RenderPass.vertices / .indices)
-    DevBuf vertices, indices, geo, col;
+    DevBuf vertices, indices, geo, geo_full, col;
     int64_t nv = 0, ni = 0;
     bool has_scene = false;
 
@@ -44,7 +44,8 @@ struct swr_context {
     DevBuf ranges, bins, bin_matrix;
     uint32_t capacity = 0;
 
-    uint32_t* h_counters = nullptr;   // pinned
+    uint32_t* h_counters = nullptr;   // pinned, mapped into the device address space
+    uint32_t* h_counters_dev = nullptr;
     // last draw (for the overflow redo and for swr_render)
     float last_m[16]{};
     uint32_t last_flags = 0;
@@ -53,8 +54,9 @@ struct swr_context {
     // timing: a ring of hipEvent sets recorded on the context stream around each kernel, so a
     // whole timed region of frames can be measured without a host sync per frame
     static constexpr int RING = 64;
-    bool timing = false;
+    int timing = 0;            // 0 off, 1 = events around k_raster only, 2 = around every stage
     hipEvent_t ev[RING][5]{};
+    int ev_level[RING]{};
     bool ev_ok = false;
     uint64_t seq = 0;          // frames enqueued with timing on
     uint64_t harvested = 0;    // frames whose events have been read
@@ -115,9 +117,11 @@ DeviceFrame make_frame(swr_context* c, const float m[16], uint32_t flags) {
     f.vertex_count = c->nv;
     f.ntri = c->ni / 3;
     f.geo = (GeomRec*)c->geo.p;
+    f.geo_full = (GeomFull*)c->geo_full.p;
     f.col = (ColRec*)c->col.p;
     uint32_t* tb = (uint32_t*)c->tilebuf.p;
     f.counters = tb;
+    f.host_counters = c->h_counters_dev;
     f.tile_count = tb + CNT_WORDS;
     f.tile_start = tb + CNT_WORDS + tiles_of(c->tg);
     f.tile_cursor = tb + CNT_WORDS + 2 * tiles_of(c->tg) + 1;
@@ -139,11 +143,13 @@ void harvest(swr_context* c) {
     for (; c->harvested < c->seq; c->harvested++) {
         hipEvent_t* ev = c->ev[c->harvested % swr_context::RING];
         float ms[5] = {0, 0, 0, 0, 0};
-        hipEventElapsedTime(&ms[0], ev[0], ev[1]);
-        hipEventElapsedTime(&ms[1], ev[1], ev[2]);
-        hipEventElapsedTime(&ms[2], ev[2], ev[3]);
+        if (c->ev_level[c->harvested % swr_context::RING] >= 2) {
+            hipEventElapsedTime(&ms[0], ev[0], ev[1]);
+            hipEventElapsedTime(&ms[1], ev[1], ev[2]);
+            hipEventElapsedTime(&ms[2], ev[2], ev[3]);
+            hipEventElapsedTime(&ms[4], ev[0], ev[4]);
+        }
         hipEventElapsedTime(&ms[3], ev[3], ev[4]);
-        hipEventElapsedTime(&ms[4], ev[0], ev[4]);
         c->last.setup_bin_ms = ms[0]; c->last.scan_ms = ms[1]; c->last.scatter_ms = ms[2];
         c->last.raster_ms = ms[3]; c->last.total_ms = ms[4];
         for (int i = 0; i < 5; i++) c->sum_ms[i] += ms[i];
@@ -167,23 +173,29 @@ int enqueue_frame(swr_context* c) {
             harvest(c);
         }
         ev = c->ev[c->seq % swr_context::RING];
+        c->ev_level[c->seq % swr_context::RING] = c->timing;
         c->seq++;
     }
-    const size_t zero_bytes = (size_t)(CNT_WORDS + tiles_of(c->tg)) * 4;
-    HIP_TRY(c, hipMemsetAsync(c->tilebuf.p, 0, zero_bytes, c->stream));
-    if (ev) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
+    if (!f.plan.use_lds || f.ntri <= 0) {
+        // global-atomic fallback: counters must start at zero.  Empty scene: no binning kernel
+        // runs at all, so the tile table (counts, starts, counters) is simply zeroed.
+        if (f.ntri <= 0) { HIP_TRY(c, hipStreamSynchronize(c->stream)); c->h_counters[CNT_PAIRS] = 0; }
+        const size_t zero_bytes = (size_t)(CNT_WORDS + 3 * tiles_of(c->tg) + 1) * 4;
+        HIP_TRY(c, hipMemsetAsync(c->tilebuf.p, 0, zero_bytes, c->stream));
+    }
+    const bool all = c->timing >= 2;
+    if (ev && all) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
     launch_setup_bin(f, c->stream);
-    if (ev) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
+    if (ev && all) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
     launch_scan(f, c->stream);
-    if (ev) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
+    if (ev && all) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
     launch_fill(f, c->stream);
     launch_sort_bins(f, c->stream);
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
     launch_raster(f, c->stream);
     if (ev) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->h_counters, f.counters, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
-    c->draw_pending = true;
+    c->draw_pending = true;   // the pair total lands in h_counters[CNT_PAIRS] (written by the scan)
     return SWR_OK;
 }
 
@@ -224,7 +236,8 @@ int swr_context_create(const swr_config* cfg, swr_context** out) {
     swr_context* c = new swr_context();
     c->device = dev;
     if ((e = hipSetDevice(dev)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipHostMalloc((void**)&c->h_counters, CNT_WORDS * 4, hipHostMallocDefault)) != hipSuccess) {
+        (e = hipHostMalloc((void**)&c->h_counters, CNT_WORDS * 4, hipHostMallocMapped)) != hipSuccess ||
+        (e = hipHostGetDevicePointer((void**)&c->h_counters_dev, c->h_counters, 0)) != hipSuccess) {
         int rc = fail(nullptr, SWR_ERR_HIP, "context init failed: %s", hipGetErrorString(e));
         delete c;
         return rc;
@@ -241,7 +254,7 @@ void swr_context_destroy(swr_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->geo, &c->col, &c->color, &c->depth, &c->tilebuf,
+    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->geo, &c->geo_full, &c->col, &c->color, &c->depth, &c->tilebuf,
                       &c->ranges, &c->bins, &c->bin_matrix};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_counters) hipHostFree(c->h_counters);
@@ -269,6 +282,7 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     if ((rc = ensure(c, c->vertices, (size_t)vertex_count * sizeof(swr_vertex)))) return rc;
     if ((rc = ensure(c, c->indices, (size_t)index_count * 8))) return rc;
     if ((rc = ensure(c, c->geo, (size_t)(index_count / 3) * sizeof(GeomRec)))) return rc;
+    if ((rc = ensure(c, c->geo_full, (size_t)(index_count / 3) * sizeof(GeomFull)))) return rc;
     if ((rc = ensure(c, c->col, (size_t)(index_count / 3) * sizeof(ColRec)))) return rc;
     if ((rc = ensure(c, c->ranges, (size_t)(index_count / 3) * sizeof(uint2)))) return rc;
     if ((rc = ensure(c, c->tilebuf, (size_t)(CNT_WORDS + 3 * std::max(1, tiles_of(c->tg)) + 1) * 4))) return rc;
@@ -380,7 +394,7 @@ int swr_timing_enable(swr_context* c, int enable) {
     if (!c) return SWR_ERR_BAD_ARG;
     int rc = swr_sync(c);
     if (rc) return rc;
-    c->timing = enable != 0;
+    c->timing = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     return SWR_OK;
 }
 

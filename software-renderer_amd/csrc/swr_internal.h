@@ -14,29 +14,38 @@ constexpr int TILE_W = 64;
 constexpr int TILE_H = 32;
 constexpr int RASTER_THREADS = 256;
 
-// Per-triangle record written by the setup kernel and gathered by the raster kernel.
-// 64 bytes = 4 x 16-byte loads.
+// Per-triangle record written by the setup kernel and gathered by the raster kernel:
+// 32 bytes = 2 x 16-byte loads.  B and C are stored relative to A as int16, which is exact for
+// every GEOM_SMALL triangle (bbox extents < 2^15); the rare others keep their absolute
+// coordinates in GeomFull.  T() is recomputed from the integer vertices where it is needed (same
+// expressions -> same bits), so it does not travel through HBM.
 struct GeomRec {
-    int32_t ax, ay, bx, by;        // truncated screen vertices A,B (Renderer.swift:251)
-    int32_t cx, cy;                // C
-    uint32_t flags;                // GEOM_* below
-    uint32_t prim;                 // primitive index (kept for debugging / resolve)
-    float t00, t01, t10, t11;      // T() = inverse([A-C | B-C]) = adj / det (Renderer.swift:95-100)
+    int32_t ax, ay;                // truncated screen vertex A (Renderer.swift:251)
+    int16_t dbx, dby;              // B - A
+    int16_t dcx, dcy;              // C - A
     float za, zb, zc;              // NDC z of a,b,c (Renderer.swift:254-256)
-    float pad;
+    uint32_t flags;                // GEOM_* below
 };
-static_assert(sizeof(GeomRec) == 64, "GeomRec must be 64 bytes");
+static_assert(sizeof(GeomRec) == 32, "GeomRec must be 32 bytes");
+
+// Absolute integer vertices, written and read only for triangles without GEOM_SMALL.
+struct GeomFull {
+    int32_t ax, ay, bx, by, cx, cy, pad0, pad1;
+};
+static_assert(sizeof(GeomFull) == 32, "GeomFull must be 32 bytes");
 
 enum : uint32_t {
     GEOM_VALID = 1u << 0,
-    GEOM_SMALL = 1u << 1,          // all |dx| < 2^15 and dy < 2^16: 32-bit span arithmetic is exact
+    GEOM_SMALL = 1u << 1,          // bbox extents < 2^15: int16 deltas and 32-bit span arithmetic are exact
     GEOM_ORD_SHIFT = 2             // 3 x 2 bits: which of a,b,c is S0,S1,S2 of the y-sorted list (:271)
 };
 
-// Vertex colours of a,b,c for the resolve pass (16-byte lanes, w unused). 48 bytes.
+// Colour-mode side record for the resolve pass: vertex colours of a,b,c (w unused) + T(). 64 bytes.
 struct ColRec {
     float4 a, b, c;
+    float4 tinv;                   // t00, t01, t10, t11
 };
+static_assert(sizeof(ColRec) == 64, "ColRec must be 64 bytes");
 
 struct Target {
     int32_t width, height;         // full framebuffer
@@ -64,10 +73,12 @@ struct DeviceFrame {
     int64_t vertex_count;
     int64_t ntri;
     GeomRec* geo;
+    GeomFull* geo_full;
     ColRec* col;
     uint32_t* tile_count;          // [tiles] (triangle,tile) pairs per tile
     uint32_t* tile_start;          // [tiles+1] exclusive scan of tile_count
     uint32_t* counters;            // [CNT_WORDS]
+    uint32_t* host_counters;       // device-visible address of the pinned host copy
     uint32_t* tile_cursor;         // [tiles] running fill position (starts as tile_start)
     uint2* ranges;                 // [ntri] band-clipped pixel bbox (x0|x1<<16, y0|y1<<16, y band-relative)
     uint32_t* bins;                // [capacity] primitive ids grouped by tile

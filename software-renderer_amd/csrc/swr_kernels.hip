@@ -134,6 +134,7 @@ struct SetupArgs {
     const int64_t* indices;
     int64_t ntri;
     GeomRec* geo;
+    GeomFull* geo_full;
     ColRec* col;            // may be null (depth-only)
     uint32_t* tile_count;
     uint2* ranges;
@@ -142,6 +143,33 @@ struct SetupArgs {
 };
 
 constexpr uint32_t RANGE_NONE_X = 0x00000001u;   // tx0 = 1, tx1 = 0: empty rectangle
+
+// T() (:95-100): columns (af - cf), (bf - cf) on (int + 0.5) floats; inverse = adjugate / determinant.
+// One definition for setup (validity), raster (weights) and resolve, so the bits always agree.
+__device__ __forceinline__ float tinv_of(int ax, int ay, int bx, int by, int cx, int cy,
+                                         float& t00, float& t01, float& t10, float& t11) {
+    const float cfx = (float)cx + 0.5f, cfy = (float)cy + 0.5f;
+    const float m00 = ((float)ax + 0.5f) - cfx, m10 = ((float)ay + 0.5f) - cfy;
+    const float m01 = ((float)bx + 0.5f) - cfx, m11 = ((float)by + 0.5f) - cfy;
+    const float det = m00 * m11 - m01 * m10;
+    t00 = m11 / det; t01 = -m01 / det; t10 = -m10 / det; t11 = m00 / det;
+    return det;
+}
+
+// Integer vertices of primitive `prim` from its compact (or, if not GEOM_SMALL, full) record.
+__device__ __forceinline__ void load_vertices(const GeomRec* __restrict__ geo, const GeomFull* __restrict__ full,
+                                              uint32_t prim, int4& q0, float4& q1, int vx[3], int vy[3]) {
+    q0 = reinterpret_cast<const int4*>(geo + prim)[0];
+    q1 = reinterpret_cast<const float4*>(geo + prim)[1];
+    vx[0] = q0.x; vy[0] = q0.y;
+    vx[1] = q0.x + (int)(short)(q0.z & 0xFFFF); vy[1] = q0.y + (q0.z >> 16);
+    vx[2] = q0.x + (int)(short)(q0.w & 0xFFFF); vy[2] = q0.y + (q0.w >> 16);
+    if (!(__float_as_uint(q1.w) & GEOM_SMALL)) {
+        const int4 f0 = reinterpret_cast<const int4*>(full + prim)[0];
+        const int4 f1 = reinterpret_cast<const int4*>(full + prim)[1];
+        vx[0] = f0.x; vy[0] = f0.y; vx[1] = f0.z; vy[1] = f0.w; vx[2] = f1.x; vy[2] = f1.y;
+    }
+}
 
 // Per-triangle work of the setup stage: the three vertex_shader calls, /w, screen map,
 // truncation, y-sort, T(); writes the 64-B GeomRec (+ ColRec) and returns the triangle's bbox
@@ -190,13 +218,9 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
 #pragma unroll
         for (int k = 0; k < 3; k++) { ix[k] = (int)sx[k]; iy[k] = (int)sy[k]; }  // :251 truncation
     }
-    // T() (:95-100): columns (af - cf), (bf - cf); inverse = adjugate / determinant
-    const float cfx = (float)ix[2] + 0.5f, cfy = (float)iy[2] + 0.5f;
-    const float m00 = ((float)ix[0] + 0.5f) - cfx, m10 = ((float)iy[0] + 0.5f) - cfy;
-    const float m01 = ((float)ix[1] + 0.5f) - cfx, m11 = ((float)iy[1] + 0.5f) - cfy;
-    const float det = m00 * m11 - m01 * m10;
+    float t00, t01, t10, t11;
+    const float det = tinv_of(ix[0], iy[0], ix[1], iy[1], ix[2], iy[2], t00, t01, t10, t11);
     ok = ok && (det != 0.0f) && (fabsf(det) < INFINITY);
-    const float t00 = m11 / det, t01 = -m01 / det, t10 = -m10 / det, t11 = m00 / det;
 
     // :271 stable 3-element insertion sort on FLOAT y
     int o0 = 0, o1 = 1, o2 = 2;
@@ -207,22 +231,28 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
     }
     const int s0y = iy[o0], s2y = iy[o2];
     const int minx = min(ix[0], min(ix[1], ix[2])), maxx = max(ix[0], max(ix[1], ix[2]));
-    // 32-bit span arithmetic is exact when every |dx| < 2^15 and every dy < 2^16
-    const bool small = ((int64_t)maxx - (int64_t)minx < 32768) && ((int64_t)s2y - (int64_t)s0y < 65536);
+    // int16 vertex deltas and 32-bit span arithmetic are exact when the bbox extents are < 2^15
+    const bool small = ((int64_t)maxx - (int64_t)minx < 32768) && ((int64_t)s2y - (int64_t)s0y < 32768);
     const uint32_t flags = (ok ? GEOM_VALID : 0u) | (small ? GEOM_SMALL : 0u) |
                            ((uint32_t)o0 << GEOM_ORD_SHIFT) | ((uint32_t)o1 << (GEOM_ORD_SHIFT + 2)) |
                            ((uint32_t)o2 << (GEOM_ORD_SHIFT + 4));
 
-    // record stores: 4 x 16 B per lane
+    // record stores: 2 x 16 B per lane (+ 2 for the rare non-small triangle, + 4 in colour mode)
     {
+        const uint32_t db = ((uint32_t)(ix[1] - ix[0]) & 0xFFFFu) | ((uint32_t)(iy[1] - iy[0]) << 16);
+        const uint32_t dc = ((uint32_t)(ix[2] - ix[0]) & 0xFFFFu) | ((uint32_t)(iy[2] - iy[0]) << 16);
         int4* gp = reinterpret_cast<int4*>(a.geo + p);
-        gp[0] = make_int4(ix[0], iy[0], ix[1], iy[1]);
-        gp[1] = make_int4(ix[2], iy[2], (int)flags, (int)(uint32_t)p);
-        reinterpret_cast<float4*>(gp)[2] = make_float4(t00, t01, t10, t11);
-        reinterpret_cast<float4*>(gp)[3] = make_float4(sz[0], sz[1], sz[2], 0.0f);
+        gp[0] = make_int4(ix[0], iy[0], (int)db, (int)dc);
+        reinterpret_cast<float4*>(gp)[1] = make_float4(sz[0], sz[1], sz[2], __uint_as_float(flags));
+        if (!small) {
+            int4* fp = reinterpret_cast<int4*>(a.geo_full + p);
+            fp[0] = make_int4(ix[0], iy[0], ix[1], iy[1]);
+            fp[1] = make_int4(ix[2], iy[2], 0, 0);
+        }
         if (a.col) {
             float4* cp = reinterpret_cast<float4*>(a.col + p);
             cp[0] = ca; cp[1] = cb; cp[2] = cc;
+            cp[3] = make_float4(t00, t01, t10, t11);
         }
     }
     // bbox ∩ band -> tiles.  Every covered pixel lies in [minx,maxx] x [S0.y,S2.y] (spans are
@@ -314,18 +344,52 @@ __global__ __launch_bounds__(256) void k_colscan(uint32_t* __restrict__ M, int G
 
 __global__ __launch_bounds__(1024) void k_fill_lds(const uint2* __restrict__ ranges, int64_t ntri,
                                                    const uint32_t* __restrict__ M,
-                                                   const uint32_t* __restrict__ tile_start,
-                                                   const uint32_t* __restrict__ counters,
+                                                   const uint32_t* __restrict__ tile_count,
+                                                   uint32_t* __restrict__ tile_start,
+                                                   uint32_t* __restrict__ counters,
+                                                   uint32_t* __restrict__ host_counters,
                                                    uint32_t* __restrict__ bins, uint32_t capacity,
                                                    int chunk, int ntiles, int tiles_x, int tag_class) {
-    extern __shared__ uint32_t cursor[];
-    if (counters[CNT_PAIRS] > capacity) return;   // overflow: the host grows the bins and redraws
+    extern __shared__ uint32_t lds[];
+    uint32_t* cursor = lds;             // [ntiles]
+    uint32_t* part = lds + ntiles;      // [1024]
+    const int t = threadIdx.x;
+    // Every workgroup scans the per-tile totals itself (16 KB from L2, ~1 us) instead of waiting
+    // for a single-workgroup scan kernel; workgroup 0 publishes tile_start and the pair total.
+    for (int e = t; e < ntiles; e += 1024) cursor[e] = tile_count[e];
+    __syncthreads();
+    const int per = (ntiles + 1023) / 1024;
+    const int sb = t * per, se = min(sb + per, ntiles);
+    uint32_t sum = 0;
+    for (int i = sb; i < se; i++) sum += cursor[i];
+    part[t] = sum;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        const uint32_t v = (t >= off) ? part[t - off] : 0u;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const uint32_t total = part[1023];
+    uint32_t run = part[t] - sum;
+    for (int i = sb; i < se; i++) { const uint32_t c = cursor[i]; cursor[i] = run; run += c; }
+    __syncthreads();
+    if (blockIdx.x == 0) {
+        for (int e = t; e < ntiles; e += 1024) tile_start[e] = cursor[e];
+        if (t == 0) {
+            tile_start[ntiles] = total;
+            counters[CNT_PAIRS] = total;                  // read by k_sort_bins / k_raster
+            counters[CNT_OVERFLOW] = total > capacity ? 1u : 0u;
+            host_counters[CNT_PAIRS] = total;             // pinned host word: no D2H copy per frame
+        }
+    }
+    if (total > capacity) return;   // overflow: the host grows the bins and redraws
     const uint32_t* row = M + (size_t)blockIdx.x * (size_t)ntiles;
-    for (int e = threadIdx.x; e < ntiles; e += blockDim.x) cursor[e] = tile_start[e] + row[e];
+    for (int e = t; e < ntiles; e += 1024) cursor[e] += row[e];
     __syncthreads();
     const int64_t p0 = (int64_t)blockIdx.x * chunk;
     const int64_t p1 = min(p0 + (int64_t)chunk, ntri);
-    for (int64_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
+    for (int64_t p = p0 + t; p < p1; p += 1024) {
         const PixBox b = unpack_box(ranges[p]);
         if (b.x0 > b.x1) continue;
         for (int ty = b.y0 / TILE_H; ty <= b.y1 / TILE_H; ty++)
@@ -376,7 +440,8 @@ __global__ __launch_bounds__(256) void k_fill(const uint2* __restrict__ ranges, 
 __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ count,
                                                uint32_t* __restrict__ start,
                                                uint32_t* __restrict__ cursor, int n,
-                                               uint32_t* counters, uint32_t capacity) {
+                                               uint32_t* counters, uint32_t* host_counters,
+                                               uint32_t capacity) {
     __shared__ uint32_t part[1024];
     const int t = threadIdx.x;
     const int per = (n + 1023) / 1024;
@@ -397,6 +462,7 @@ __global__ __launch_bounds__(1024) void k_scan(const uint32_t* __restrict__ coun
     if (t == 1023) {
         start[n] = part[1023];
         counters[CNT_PAIRS] = part[1023];                  // total (triangle,tile) pairs of the frame
+        host_counters[CNT_PAIRS] = part[1023];             // pinned host word: no D2H copy per frame
         if (part[1023] > capacity) counters[CNT_OVERFLOW] = 1u;
     }
 }
@@ -457,6 +523,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_bins(uint32_t* __restrict
 // ------------------------------------------------------------------------------------------
 struct RasterArgs {
     const GeomRec* geo;
+    const GeomFull* geo_full;
     const ColRec* col;
     const uint32_t* tile_start;
     const uint32_t* bins;
@@ -501,16 +568,12 @@ __device__ __forceinline__ void fragment(unsigned long long* keys, const TriStat
     atomicMin(&keys[lidx], key);
 }
 
-__device__ __forceinline__ void load_tri(const GeomRec* __restrict__ geo, uint32_t prim, TriState& t,
-                                         int& minx, int& maxx) {
-    const int4* gp = reinterpret_cast<const int4*>(geo + prim);
-    const int4 q0 = gp[0];
-    const int4 q1 = gp[1];
-    const float4 q2 = reinterpret_cast<const float4*>(gp)[2];
-    const float4 q3 = reinterpret_cast<const float4*>(gp)[3];
-    const int vx[3] = {q0.x, q0.z, q1.x};
-    const int vy[3] = {q0.y, q0.w, q1.y};
-    const uint32_t fl = (uint32_t)q1.z;
+__device__ __forceinline__ void load_tri(const GeomRec* __restrict__ geo, const GeomFull* __restrict__ full,
+                                         uint32_t prim, TriState& t, int& minx, int& maxx) {
+    int4 q0; float4 q1;
+    int vx[3], vy[3];
+    load_vertices(geo, full, prim, q0, q1, vx, vy);
+    const uint32_t fl = __float_as_uint(q1.w);
     const int o0 = (fl >> GEOM_ORD_SHIFT) & 3, o1 = (fl >> (GEOM_ORD_SHIFT + 2)) & 3,
               o2 = (fl >> (GEOM_ORD_SHIFT + 4)) & 3;
     // select without dynamic indexing (keeps the arrays in registers)
@@ -522,11 +585,11 @@ __device__ __forceinline__ void load_tri(const GeomRec* __restrict__ geo, uint32
     t.ch.r01 = __builtin_amdgcn_rcpf((float)(t.ch.s1y - t.ch.s0y));
     t.ch.r12 = __builtin_amdgcn_rcpf((float)(t.ch.s2y - t.ch.s1y));
     t.ch.r02 = __builtin_amdgcn_rcpf((float)(t.ch.s2y - t.ch.s0y));
-    t.cfx = (float)q1.x + 0.5f;
-    t.cfy = (float)q1.y + 0.5f;
-    t.cx = q1.x;
-    t.t00 = q2.x; t.t01 = q2.y; t.t10 = q2.z; t.t11 = q2.w;
-    t.za = q3.x; t.zb = q3.y; t.zc = q3.z;
+    t.cfx = (float)vx[2] + 0.5f;
+    t.cfy = (float)vy[2] + 0.5f;
+    t.cx = vx[2];
+    tinv_of(vx[0], vy[0], vx[1], vy[1], vx[2], vy[2], t.t00, t.t01, t.t10, t.t11);
+    t.za = q1.x; t.zb = q1.y; t.zc = q1.z;
     t.prim = prim;
     minx = min(vx[0], min(vx[1], vx[2]));
     maxx = max(vx[0], max(vx[1], vx[2]));
@@ -618,7 +681,7 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
         bool big = false;
         if (have) {
             int minx, maxx;
-            load_tri(a.geo, a.bins[b0 + e], t, minx, maxx);
+            load_tri(a.geo, a.geo_full, a.bins[b0 + e], t, minx, maxx);
             ya = max(t.ch.s0y, Y0);
             yb = min(t.ch.s2y, Y1);
             bxa = max(minx, X0);
@@ -809,11 +872,14 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
                     need_rec = need_rec || (d == 0.0f);   // sign of zero comes from the winner
                 }
                 if (need_rec) {
-                    const int4* gp = reinterpret_cast<const int4*>(a.geo + prim);
-                    const int4 q1 = gp[1];
-                    const float4 q2 = reinterpret_cast<const float4*>(gp)[2];
-                    const float4 q3 = reinterpret_cast<const float4*>(gp)[3];
-                    const float cfx = (float)q1.x + 0.5f, cfy = (float)q1.y + 0.5f;
+                    int4 g0; float4 q3;
+                    int vx[3], vy[3];
+                    load_vertices(a.geo, a.geo_full, prim, g0, q3, vx, vy);
+                    float4 q2;   // T(): from the colour record when there is one, else recomputed
+                    const float4* cp = reinterpret_cast<const float4*>(a.col + prim);
+                    if (want_color) q2 = cp[3];
+                    else tinv_of(vx[0], vy[0], vx[1], vy[1], vx[2], vy[2], q2.x, q2.y, q2.z, q2.w);
+                    const float cfx = (float)vx[2] + 0.5f, cfy = (float)vy[2] + 0.5f;
                     const float dx = ((float)(x + k) + 0.5f) - cfx;
                     const float dy = ((float)y + 0.5f) - cfy;
                     const float w0 = q2.x * dx + q2.y * dy;
@@ -821,7 +887,6 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
                     const float w2 = 1.0f - w0 - w1;
                     if (ZTEST) d = q3.x * w0 + q3.y * w1 + q3.z * w2;
                     if (want_color) {
-                        const float4* cp = reinterpret_cast<const float4*>(a.col + prim);
                         const float4 ca = cp[0], cb = cp[1], cc = cp[2];
                         VertexOut vin;
                         vin.pos = make_float4((float)(x + k) + 0.5f, (float)y + 0.5f, d, 1.0f);
@@ -870,7 +935,7 @@ void launch_validate_indices(const int64_t* indices, int64_t count, int64_t vert
 static SetupArgs make_setup_args(const DeviceFrame& f) {
     SetupArgs a;
     a.vertices = f.vertices; a.indices = f.indices; a.ntri = f.ntri;
-    a.geo = f.geo; a.col = (f.flags & SWR_FLAG_NO_COLOR) ? nullptr : f.col;
+    a.geo = f.geo; a.geo_full = f.geo_full; a.col = (f.flags & SWR_FLAG_NO_COLOR) ? nullptr : f.col;
     a.tile_count = f.tile_count; a.ranges = f.ranges; a.tg = f.tg;
     for (int c = 0; c < 4; c++)
         a.m.columns[c] = make_float4(f.m[4 * c + 0], f.m[4 * c + 1], f.m[4 * c + 2], f.m[4 * c + 3]);
@@ -914,17 +979,19 @@ void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
 }
 
 void launch_scan(const DeviceFrame& f, hipStream_t s) {
+    if (f.plan.use_lds && f.ntri > 0) return;   // LDS path: the scan is fused into k_fill_lds
     const int n = f.tg.tiles_x * f.tg.tiles_y;
     hipLaunchKernelGGL(k_scan, dim3(1), dim3(1024), 0, s, f.tile_count, f.tile_start, f.tile_cursor, n,
-                       f.counters, f.capacity);
+                       f.counters, f.host_counters, f.capacity);
 }
 
 void launch_fill(const DeviceFrame& f, hipStream_t s) {
     if (f.ntri <= 0) return;
     const int ntiles = f.tg.tiles_x * f.tg.tiles_y;
     if (f.plan.use_lds) {
-        hipLaunchKernelGGL(k_fill_lds, dim3(f.plan.G), dim3(1024), f.plan.lds_bytes, s, f.ranges, f.ntri,
-                           f.bin_matrix, f.tile_start, f.counters, f.bins, f.capacity, f.plan.chunk, ntiles,
+        hipLaunchKernelGGL(k_fill_lds, dim3(f.plan.G), dim3(1024), f.plan.lds_bytes + 4096, s, f.ranges, f.ntri,
+                           f.bin_matrix, f.tile_count, f.tile_start, f.counters, f.host_counters, f.bins,
+                           f.capacity, f.plan.chunk, ntiles,
                            f.tg.tiles_x, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
     } else {
         const unsigned blocks = (unsigned)((f.ntri + 255) / 256);
@@ -942,7 +1009,7 @@ void launch_sort_bins(const DeviceFrame& f, hipStream_t s) {
 
 void launch_raster(const DeviceFrame& f, hipStream_t s) {
     RasterArgs a;
-    a.geo = f.geo; a.col = f.col; a.tile_start = f.tile_start; a.bins = f.bins;
+    a.geo = f.geo; a.geo_full = f.geo_full; a.col = f.col; a.tile_start = f.tile_start; a.bins = f.bins;
     a.counters = f.counters; a.capacity = f.capacity;
     a.color = (f.flags & SWR_FLAG_NO_COLOR) ? nullptr : f.color;
     a.depth = f.depth; a.tg = f.tg;

@@ -32,7 +32,7 @@ struct swr_context {
     std::string err;
 
     // scene (RenderPass.vertices / .indices)
-    DevBuf vertices, indices, geo, geo_full, col;
+    DevBuf vertices, indices, xyz, rgb, idx32, geo, geo_full, col;
     int64_t nv = 0, ni = 0;
     bool has_scene = false;
 
@@ -114,6 +114,9 @@ DeviceFrame make_frame(swr_context* c, const float m[16], uint32_t flags) {
     DeviceFrame f{};
     f.vertices = (const swr_vertex*)c->vertices.p;
     f.indices = (const int64_t*)c->indices.p;
+    f.xyz = (const float4*)c->xyz.p;
+    f.rgb = (const float4*)c->rgb.p;
+    f.idx32 = (const uint32_t*)c->idx32.p;
     f.vertex_count = c->nv;
     f.ntri = c->ni / 3;
     f.geo = (GeomRec*)c->geo.p;
@@ -254,7 +257,7 @@ void swr_context_destroy(swr_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->geo, &c->geo_full, &c->col, &c->color, &c->depth, &c->tilebuf,
+    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->xyz, &c->rgb, &c->idx32, &c->geo, &c->geo_full, &c->col, &c->color, &c->depth, &c->tilebuf,
                       &c->ranges, &c->bins, &c->bin_matrix};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_counters) hipHostFree(c->h_counters);
@@ -272,8 +275,8 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
         return fail(c, SWR_ERR_BAD_ARG, "swr_scene_upload: bad vertex/index arguments");
     if (index_count % 3 != 0)                                     // assert, Renderer.swift:209
         return fail(c, SWR_ERR_INDEX_COUNT, "index_count %lld is not a multiple of 3", (long long)index_count);
-    if (index_count / 3 >= 0xFFFFFFFFll)
-        return fail(c, SWR_ERR_UNSUPPORTED, "more than 2^32-2 primitives");
+    if (index_count / 3 >= 0xFFFFFFFFll || vertex_count > 0xFFFFFFFFll)
+        return fail(c, SWR_ERR_UNSUPPORTED, "more than 2^32-2 primitives or 2^32 vertices");
     HIP_TRY(c, hipSetDevice(c->device));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->has_scene = false;
@@ -281,6 +284,9 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     int rc;
     if ((rc = ensure(c, c->vertices, (size_t)vertex_count * sizeof(swr_vertex)))) return rc;
     if ((rc = ensure(c, c->indices, (size_t)index_count * 8))) return rc;
+    if ((rc = ensure(c, c->xyz, (size_t)vertex_count * 16))) return rc;
+    if ((rc = ensure(c, c->rgb, (size_t)vertex_count * 16))) return rc;
+    if ((rc = ensure(c, c->idx32, (size_t)index_count * 4))) return rc;
     if ((rc = ensure(c, c->geo, (size_t)(index_count / 3) * sizeof(GeomRec)))) return rc;
     if ((rc = ensure(c, c->geo_full, (size_t)(index_count / 3) * sizeof(GeomFull)))) return rc;
     if ((rc = ensure(c, c->col, (size_t)(index_count / 3) * sizeof(ColRec)))) return rc;
@@ -294,6 +300,8 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     // index range check (Swift array subscript would trap, Renderer.swift:226)
     HIP_TRY(c, hipMemsetAsync(c->tilebuf.p, 0, CNT_WORDS * 4, c->stream));
     launch_validate_indices((const int64_t*)c->indices.p, index_count, vertex_count, (uint32_t*)c->tilebuf.p, c->stream);
+    launch_split_scene((const swr_vertex*)c->vertices.p, vertex_count, (const int64_t*)c->indices.p, index_count,
+                       (float4*)c->xyz.p, (float4*)c->rgb.p, (uint32_t*)c->idx32.p, c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->tilebuf.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -68,8 +68,11 @@ BinPlan plan_binning(int64_t ntri, int ntiles);
 // Everything one frame needs, all device pointers.  colour/depth are band-local: element
 // (x, y) of the full image lives at [(y - row_begin) * width + x].
 struct DeviceFrame {
-    const swr_vertex* vertices;
+    const swr_vertex* vertices;    // as uploaded (AoS)
     const int64_t* indices;
+    const float4* xyz;             // [nv] split positions
+    const float4* rgb;             // [nv] split colours
+    const uint32_t* idx32;         // [ni] narrowed indices
     int64_t vertex_count;
     int64_t ntri;
     GeomRec* geo;
@@ -94,6 +97,8 @@ struct DeviceFrame {
 
 void launch_validate_indices(const int64_t* indices, int64_t count, int64_t vertex_count,
                              uint32_t* counters, hipStream_t s);
+void launch_split_scene(const swr_vertex* v, int64_t nv, const int64_t* idx, int64_t ni, float4* xyz,
+                        float4* rgb, uint32_t* idx32, hipStream_t s);
 void launch_setup_bin(const DeviceFrame& f, hipStream_t s);
 void launch_scan(const DeviceFrame& f, hipStream_t s);
 void launch_fill(const DeviceFrame& f, hipStream_t s);

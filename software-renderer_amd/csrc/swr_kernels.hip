@@ -175,10 +175,16 @@ __device__ __forceinline__ float tinv_of(int ax, int ay, int bx, int by, int cx,
 }
 
 // Integer vertices of primitive `prim` from its compact (or, if not GEOM_SMALL, full) record.
+__device__ __forceinline__ void decode_vertices(const GeomFull* __restrict__ full, uint32_t prim,
+                                                const int4& q0, const float4& q1, int vx[3], int vy[3]);
 __device__ __forceinline__ void load_vertices(const GeomRec* __restrict__ geo, const GeomFull* __restrict__ full,
                                               uint32_t prim, int4& q0, float4& q1, int vx[3], int vy[3]) {
     q0 = reinterpret_cast<const int4*>(geo + prim)[0];
     q1 = reinterpret_cast<const float4*>(geo + prim)[1];
+    decode_vertices(full, prim, q0, q1, vx, vy);
+}
+__device__ __forceinline__ void decode_vertices(const GeomFull* __restrict__ full, uint32_t prim,
+                                                const int4& q0, const float4& q1, int vx[3], int vy[3]) {
     vx[0] = q0.x; vy[0] = q0.y;
     vx[1] = q0.x + (int)(short)(q0.z & 0xFFFF); vy[1] = q0.y + (q0.z >> 16);
     vx[2] = q0.x + (int)(short)(q0.w & 0xFFFF); vy[2] = q0.y + (q0.w >> 16);
@@ -585,11 +591,10 @@ __device__ __forceinline__ void fragment(unsigned long long* keys, const TriStat
     atomicMin(&keys[lidx], key);
 }
 
-__device__ __forceinline__ void load_tri(const GeomRec* __restrict__ geo, const GeomFull* __restrict__ full,
-                                         uint32_t prim, TriState& t, int& minx, int& maxx) {
-    int4 q0; float4 q1;
+__device__ __forceinline__ void load_tri(const GeomFull* __restrict__ full, uint32_t prim, const int4& q0,
+                                         const float4& q1, TriState& t, int& minx, int& maxx) {
     int vx[3], vy[3];
-    load_vertices(geo, full, prim, q0, q1, vx, vy);
+    decode_vertices(full, prim, q0, q1, vx, vy);
     const uint32_t fl = __float_as_uint(q1.w);
     const int o0 = (fl >> GEOM_ORD_SHIFT) & 3, o1 = (fl >> (GEOM_ORD_SHIFT + 2)) & 3,
               o2 = (fl >> (GEOM_ORD_SHIFT + 4)) & 3;
@@ -679,17 +684,28 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
     const int X1 = min(X0 + TILE_W, a.tg.width) - 1;
     const int Y1 = min(Y0 + TILE_H, a.tg.row_end) - 1;
 
+    const bool overflow = a.counters[CNT_PAIRS] > a.capacity;
+    const uint32_t b0 = overflow ? 0u : a.tile_start[tile];
+    const uint32_t b1 = overflow ? 0u : a.tile_start[tile + 1];
+    const uint32_t m = b1 - b0;   // bin already sorted by size class (k_sort_bins), heaviest first
+
+    // the gather chain of the first batch (bin entry -> record) is issued before the LDS init so
+    // that its latency overlaps the init and the barrier
+    uint32_t prim_pre = 0u;
+    int4 q0_pre = make_int4(0, 0, 0, 0);
+    float4 q1_pre = make_float4(0, 0, 0, 0);
+    if ((uint32_t)tid < m && VAR != 9 && VAR != 11) {
+        prim_pre = a.bins[b0 + tid];
+        q0_pre = reinterpret_cast<const int4*>(a.geo + prim_pre)[0];
+        q1_pre = reinterpret_cast<const float4*>(a.geo + prim_pre)[1];
+    }
+
     // clear fused into the LDS init (Renderer.clear :205-206, :232-236)
     for (int i = tid; i < TILE_W * TILE_H; i += RASTER_THREADS) keys[i] = KEY_EMPTY;
     for (int i = lane; i < 64 * SUPER; i += 64) span_mark[tid >> 6][i] = 0u;
     int tag = 0;               // marker generation of this wave (25 bits: never wraps in one launch)
     __syncthreads();
 
-    const bool overflow = a.counters[CNT_PAIRS] > a.capacity;
-    const uint32_t b0 = overflow ? 0u : a.tile_start[tile];
-    const uint32_t b1 = overflow ? 0u : a.tile_start[tile + 1];
-
-    const uint32_t m = b1 - b0;   // bin already sorted by size class (k_sort_bins), heaviest first
     for (uint32_t base0 = 0; VAR != 9 && VAR != 11 && base0 < m; base0 += RASTER_THREADS) {
         const uint32_t e = base0 + tid;
         const bool have = e < m;
@@ -698,7 +714,15 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
         bool big = false;
         if (have) {
             int minx, maxx;
-            load_tri(a.geo, a.geo_full, a.bins[b0 + e], t, minx, maxx);
+            uint32_t prim = prim_pre;
+            int4 q0 = q0_pre;
+            float4 q1 = q1_pre;
+            if (base0 != 0) {
+                prim = a.bins[b0 + e];
+                q0 = reinterpret_cast<const int4*>(a.geo + prim)[0];
+                q1 = reinterpret_cast<const float4*>(a.geo + prim)[1];
+            }
+            load_tri(a.geo_full, prim, q0, q1, t, minx, maxx);
             ya = max(t.ch.s0y, Y0);
             yb = min(t.ch.s2y, Y1);
             bxa = max(minx, X0);

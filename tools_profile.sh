@@ -6,7 +6,7 @@ R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/profile
 rm -rf $OUT && mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline > $OUT/stats_bench.json 2> $OUT/stats.log &&
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $R/bench.py --steps 100 --warmup 10 --no-cpu-baseline --no-extra > $OUT/stats_bench.json 2> $OUT/stats.log &&
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/fetch -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra > $OUT/fetch.log 2>&1 &&
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/write -- python3 $R/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-extra > $OUT/write.log 2>&1 &&
 python3 - <<PY

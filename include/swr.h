@@ -28,10 +28,10 @@ extern "C" {
 enum {
     SWR_OK = 0,
     SWR_ERR_BAD_ARG = -1,       /* null pointer, non-positive size, bad band */
-    SWR_ERR_INDEX_COUNT = -2,   /* index_count % 3 != 0   (assert, Renderer.swift:209) */
+    SWR_ERR_INDEX_COUNT = -2,   /* index_count % verticesCount != 0   (assert, Renderer.swift:209) */
     SWR_ERR_INDEX_RANGE = -3,   /* an index outside [0, vertex_count)  (Swift array trap, Renderer.swift:226) */
     SWR_ERR_HIP = -4,           /* HIP runtime error / no device */
-    SWR_ERR_UNSUPPORTED = -5,   /* primitive type not on the hot path (.line / .vertices), too many primitives */
+    SWR_ERR_UNSUPPORTED = -5,   /* unknown primitive type, too many primitives / vertices */
     SWR_ERR_NO_SCENE = -6,      /* swr_draw before swr_scene_upload / swr_target_set */
     SWR_ERR_NOMEM = -7
 };
@@ -40,7 +40,7 @@ enum {
 enum {
     SWR_PRIMITIVE_TRIANGLE = 0,
     SWR_PRIMITIVE_LINE = 1,      /* reference draw(line:) is an empty stub, Renderer.swift:289-293 */
-    SWR_PRIMITIVE_VERTICES = 2   /* Renderer.swift:295-302 — out of scope this round */
+    SWR_PRIMITIVE_VERTICES = 2   /* Renderer.swift:295-302: point plotting */
 };
 
 /* ---- draw flags --------------------------------------------------------------------- */
@@ -136,6 +136,10 @@ int swr_target_set(swr_context* ctx, int64_t width, int64_t height,
 /* One frame: clear + all triangles (Renderer.swift:204-230) into the device-resident band.
  * Asynchronous on the context stream; swr_sync() or a swr_read_* completes it. */
 int swr_draw(swr_context* ctx, const float transform[16], uint32_t flags);
+/* Same with RenderPass.primitiveType (Renderer.swift:197, :210-219): .triangle = swr_draw;
+ * .vertices plots every vertex reference as a point (Renderer.swift:295-302); .line clears only
+ * (the reference's draw(line:) is an empty stub, Renderer.swift:289-293). */
+int swr_draw_primitives(swr_context* ctx, const float transform[16], uint32_t flags, int32_t primitive_type);
 int swr_sync(swr_context* ctx);
 
 /* Copy the band's rows into the caller's FULL-size host images (rows [row_begin,row_end) of

@@ -45,6 +45,11 @@ def lib():
                                   ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                   ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int64, ctypes.c_int64,
                                   ctypes.POINTER(Stats)]
+        L.swro_render_primitives.restype = ctypes.c_int
+        L.swro_render_primitives.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                                             ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
+                                             ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int64,
+                                             ctypes.c_int64, ctypes.POINTER(Stats)]
         L.swro_interpolate.restype = ctypes.c_int64
         L.swro_interpolate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]
         L.swro_quantise.restype = ctypes.c_uint8
@@ -55,7 +60,7 @@ def lib():
 
 def render(vertices: np.ndarray, indices: np.ndarray, transform: np.ndarray, width: int, height: int,
            flags: int = 0, row_begin: int = 0, row_end: int | None = None,
-           color: np.ndarray | None = None, depth: np.ndarray | None = None):
+           color: np.ndarray | None = None, depth: np.ndarray | None = None, primitive_type: int = 0):
     """Returns (color uint8[H,W,4] BGRA or None, depth float32[H,W], Stats, rc)."""
     L = lib()
     v = np.ascontiguousarray(vertices, dtype=np.float32)
@@ -68,10 +73,10 @@ def render(vertices: np.ndarray, indices: np.ndarray, transform: np.ndarray, wid
     if depth is None:
         depth = np.full((height, width), -123.0, dtype=np.float32)
     st = Stats()
-    rc = L.swro_render(color.ctypes.data if color is not None else None, depth.ctypes.data,
-                       width, height, v.ctypes.data, v.shape[0] if v.ndim == 2 else v.size // 8,
-                       i.ctypes.data, i.size, m.ctypes.data, flags, row_begin, row_end,
-                       ctypes.byref(st))
+    rc = L.swro_render_primitives(color.ctypes.data if color is not None else None, depth.ctypes.data,
+                                  width, height, v.ctypes.data, v.shape[0] if v.ndim == 2 else v.size // 8,
+                                  i.ctypes.data, i.size, m.ctypes.data, flags, primitive_type, row_begin, row_end,
+                                  ctypes.byref(st))
     return color, depth, st, rc
 
 

@@ -226,3 +226,60 @@ int swro_render(uint8_t* color, float* depth, int64_t W, int64_t H,
     if (stats) *stats = f.st;
     return 0;
 }
+
+/* Renderer.render with primitiveType .line / .vertices (Renderer.swift:210-229, :289-302). */
+int swro_render_primitives(uint8_t* color, float* depth, int64_t W, int64_t H,
+                           const swro_vertex* vertices, int64_t vertex_count,
+                           const int64_t* indices, int64_t index_count,
+                           const float M[16], uint32_t flags, int32_t primitive_type,
+                           int64_t row_begin, int64_t row_end, swro_stats* stats) {
+    if (primitive_type == 0)
+        return swro_render(color, depth, W, H, vertices, vertex_count, indices, index_count, M, flags,
+                           row_begin, row_end, stats);
+    if (primitive_type != 1 && primitive_type != 2) return -5;
+    if (!depth || W <= 0 || H <= 0 || !M) return -1;
+    if (!(flags & SWRO_NO_COLOR) && !color) return -1;
+    if (index_count < 0 || vertex_count < 0) return -1;
+    if (index_count > 0 && (!indices || !vertices)) return -1;
+    const int per = primitive_type == 1 ? 2 : 3;                  /* verticesCount :179-188 */
+    if (index_count % per != 0) return -2;                        /* :209 */
+    if (row_begin < 0 || row_end > H || row_begin > row_end) return -1;
+    for (int64_t i = 0; i < index_count; i++)
+        if (indices[i] < 0 || indices[i] >= vertex_count) return -3;
+    swro_stats st;
+    memset(&st, 0, sizeof st);
+    /* clear (:205-206) */
+    if (!(flags & SWRO_NO_COLOR))
+        memset(color + (size_t)row_begin * (size_t)W * 4, 0, (size_t)(row_end - row_begin) * (size_t)W * 4);
+    for (int64_t i = row_begin * W; i < row_end * W; i++) depth[i] = INFINITY;
+    if (primitive_type == 2 && !(flags & SWRO_NO_COLOR)) {
+        float fw = (float)W, fh = (float)H;
+        for (int64_t i = 0; i < index_count; i++) {               /* :222-229 then :296-301 */
+            const swro_vertex* v = &vertices[indices[i]];
+            float x = v->xyz[0], y = v->xyz[1], z = v->xyz[2];
+            float r[4];
+            for (int c = 0; c < 4; c++) {
+                float a = M[0 + c] * x;
+                a = a + M[4 + c] * y;
+                a = a + M[8 + c] * z;
+                a = a + M[12 + c] * 1.0f;
+                r[c] = a;
+            }
+            float nx = r[0] / r[3], ny = r[1] / r[3];
+            float sx = (nx * 0.5f + 0.5f) * fw;                   /* convertedToScreen :165-171 */
+            float sy = (ny * -0.5f + 0.5f) * fh;
+            if (!(fabsf(sx) < COORD_LIMIT) || !(fabsf(sy) < COORD_LIMIT)) { st.triangles_skipped++; continue; }
+            int64_t px = (int64_t)sx, py = (int64_t)sy;           /* Int(v.xyz.x) :298-299 */
+            if (px < 0 || px >= W || py < row_begin || py >= row_end) continue;   /* setter drops OOB :30-36 */
+            st.fragments++;
+            st.fragments_written++;
+            uint8_t* p = color + (size_t)(py * W + px) * 4;       /* Pixel(float3: vertex.color) :300 */
+            p[0] = swro_quantise(v->color[2]);
+            p[1] = swro_quantise(v->color[1]);
+            p[2] = swro_quantise(v->color[0]);
+            p[3] = swro_quantise(1.0f);
+        }
+    }
+    if (stats) *stats = st;
+    return 0;
+}

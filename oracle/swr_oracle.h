@@ -52,6 +52,20 @@ int swro_render(uint8_t* color, float* depth, int64_t W, int64_t H,
                 const float transform[16], uint32_t flags,
                 int64_t row_begin, int64_t row_end, swro_stats* stats);
 
+/* Same, with RenderPass.primitiveType (Renderer.swift:174-189, :210-219):
+ *   0 = .triangle  -> swro_render
+ *   1 = .line      -> draw(line:) is an empty stub (Renderer.swift:289-293): the frame is only cleared;
+ *                     index_count must be a multiple of 2 (verticesCount, :183-184)
+ *   2 = .vertices  -> draw(vertices:) (Renderer.swift:295-302): every transformed vertex of every
+ *                     3-index primitive is plotted at (Int(sx), Int(sy)) with its own colour, in index
+ *                     order (later vertices overwrite), no z; off-screen points are dropped (:30-36).
+ *                     Deviation: a non-finite / |coord| >= 2^30 point is skipped (Swift would trap). */
+int swro_render_primitives(uint8_t* color, float* depth, int64_t W, int64_t H,
+                           const swro_vertex* vertices, int64_t vertex_count,
+                           const int64_t* indices, int64_t index_count,
+                           const float transform[16], uint32_t flags, int32_t primitive_type,
+                           int64_t row_begin, int64_t row_end, swro_stats* stats);
+
 /* Renderer.interpolate(values:t:) (Renderer.swift:467-494), exposed for unit tests.
  * pts = n (x,y) pairs, n in {2,3}. */
 int64_t swro_interpolate(const int64_t* pts_xy, int n, int64_t t);

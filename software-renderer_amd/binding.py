@@ -16,7 +16,7 @@ FLAG_NO_COLOR = 2
 # every symbol include/swr.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
     "swr_abi_version", "swr_version", "swr_context_create", "swr_context_destroy", "swr_last_error",
-    "swr_render", "swr_scene_upload", "swr_target_set", "swr_draw", "swr_sync", "swr_read_color",
+    "swr_render", "swr_scene_upload", "swr_target_set", "swr_draw", "swr_draw_primitives", "swr_sync", "swr_read_color",
     "swr_read_depth", "swr_timing_enable", "swr_get_timings", "swr_timing_totals", "swr_timing_reset", "swr_tile_rows", "swr_tile_cols",
     "swr_band_rows",
 ]
@@ -92,6 +92,8 @@ def load_library():
     L.swr_scene_upload.argtypes = [vp, vp, i64, vp, i64]
     L.swr_target_set.argtypes = [vp, i64, i64, i64, i64]
     L.swr_draw.argtypes = [vp, vp, u32]
+    L.swr_draw_primitives.argtypes = [vp, vp, u32, i32]
+    L.swr_draw_primitives.restype = ctypes.c_int
     L.swr_sync.argtypes = [vp]
     L.swr_read_color.argtypes = [vp, vp]
     L.swr_read_depth.argtypes = [vp, vp]
@@ -168,9 +170,9 @@ class Context:
         self._check(self._L.swr_target_set(self._h, width, height, row_begin, row_end))
         self.width, self.height, self.row_begin, self.row_end = width, height, row_begin, row_end
 
-    def draw(self, transform: np.ndarray, flags: int = 0):
+    def draw(self, transform: np.ndarray, flags: int = 0, primitive_type: int = 0):
         m = np.ascontiguousarray(transform, dtype=np.float32).reshape(16)
-        self._check(self._L.swr_draw(self._h, m.ctypes.data, flags))
+        self._check(self._L.swr_draw_primitives(self._h, m.ctypes.data, flags, primitive_type))
 
     def sync(self):
         self._check(self._L.swr_sync(self._h))

@@ -49,6 +49,7 @@ struct swr_context {
     // last draw (for the overflow redo and for swr_render)
     float last_m[16]{};
     uint32_t last_flags = 0;
+    int last_prim = SWR_PRIMITIVE_TRIANGLE;
     bool draw_pending = false;
 
     // timing: a ring of hipEvent sets recorded on the context stream around each kernel, so a
@@ -169,6 +170,15 @@ int enqueue_frame(swr_context* c) {
         }
     }
     DeviceFrame f = make_frame(c, c->last_m, c->last_flags);
+    if (c->last_prim != SWR_PRIMITIVE_TRIANGLE) {
+        // .vertices / .line: three small kernels, no binning; the pair counter reads 0
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->h_counters[CNT_PAIRS] = 0;
+        launch_points_or_lines(f, c->last_prim, c->stream);
+        HIP_TRY(c, hipGetLastError());
+        c->draw_pending = true;
+        return SWR_OK;
+    }
     hipEvent_t* ev = nullptr;
     if (c->timing) {
         if (c->seq - c->harvested >= (uint64_t)swr_context::RING) {   // ring full: drain it
@@ -205,6 +215,8 @@ int enqueue_frame(swr_context* c) {
 }  // namespace
 
 extern "C" {
+
+int swr_draw_primitives(swr_context* c, const float transform[16], uint32_t flags, int32_t primitive_type);
 
 int swr_abi_version(void) { return SWR_ABI_VERSION; }
 const char* swr_version(void) { return "swr-hip gfx950 0.1 (tile 64x32, wave64 LDS visibility keys)"; }
@@ -273,8 +285,6 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     if (!c) return SWR_ERR_BAD_ARG;
     if (vertex_count < 0 || index_count < 0 || (index_count > 0 && (!indices || !vertices)))
         return fail(c, SWR_ERR_BAD_ARG, "swr_scene_upload: bad vertex/index arguments");
-    if (index_count % 3 != 0)                                     // assert, Renderer.swift:209
-        return fail(c, SWR_ERR_INDEX_COUNT, "index_count %lld is not a multiple of 3", (long long)index_count);
     if (index_count / 3 >= 0xFFFFFFFFll || vertex_count > 0xFFFFFFFFll)
         return fail(c, SWR_ERR_UNSUPPORTED, "more than 2^32-2 primitives or 2^32 vertices");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -340,7 +350,19 @@ int swr_target_set(swr_context* c, int64_t width, int64_t height, int64_t row_be
 }
 
 int swr_draw(swr_context* c, const float transform[16], uint32_t flags) {
+    return swr_draw_primitives(c, transform, flags, SWR_PRIMITIVE_TRIANGLE);
+}
+
+int swr_draw_primitives(swr_context* c, const float transform[16], uint32_t flags, int32_t primitive_type) {
     if (!c || !transform) return SWR_ERR_BAD_ARG;
+    if (primitive_type != SWR_PRIMITIVE_TRIANGLE && primitive_type != SWR_PRIMITIVE_LINE &&
+        primitive_type != SWR_PRIMITIVE_VERTICES)
+        return fail(c, SWR_ERR_UNSUPPORTED, "unknown primitive type %d", primitive_type);
+    {
+        const int per = primitive_type == SWR_PRIMITIVE_LINE ? 2 : 3;          // verticesCount, Renderer.swift:179-188
+        if (c->has_scene && c->ni % per != 0)                                  // assert, Renderer.swift:209
+            return fail(c, SWR_ERR_INDEX_COUNT, "index_count %lld is not a multiple of %d", (long long)c->ni, per);
+    }
     if (!c->has_scene || !c->has_target)
         return fail(c, SWR_ERR_NO_SCENE, "swr_draw needs swr_scene_upload and swr_target_set first");
     if (flags & ~(uint32_t)(SWR_FLAG_DEPTH_TEST | SWR_FLAG_NO_COLOR))
@@ -348,6 +370,7 @@ int swr_draw(swr_context* c, const float transform[16], uint32_t flags) {
     HIP_TRY(c, hipSetDevice(c->device));
     memcpy(c->last_m, transform, sizeof c->last_m);
     c->last_flags = flags;
+    c->last_prim = primitive_type;
     return enqueue_frame(c);
 }
 
@@ -437,14 +460,18 @@ int swr_get_timings(swr_context* c, swr_timings* out) {
 
 int swr_render(swr_context* c, const swr_render_pass* p) {
     if (!c || !p) return SWR_ERR_BAD_ARG;
-    if (p->primitive_type != SWR_PRIMITIVE_TRIANGLE)
-        return fail(c, SWR_ERR_UNSUPPORTED, "primitive type %d is not on the triangle hot path", p->primitive_type);
+    if (p->primitive_type != SWR_PRIMITIVE_TRIANGLE && p->primitive_type != SWR_PRIMITIVE_LINE &&
+        p->primitive_type != SWR_PRIMITIVE_VERTICES)
+        return fail(c, SWR_ERR_UNSUPPORTED, "unknown primitive type %d", p->primitive_type);
+    if (p->index_count >= 0 && p->index_count % (p->primitive_type == SWR_PRIMITIVE_LINE ? 2 : 3) != 0)   // Renderer.swift:209
+        return fail(c, SWR_ERR_INDEX_COUNT, "index_count %lld is not a multiple of %d", (long long)p->index_count,
+                    p->primitive_type == SWR_PRIMITIVE_LINE ? 2 : 3);
     if (!p->depth || (!(p->flags & SWR_FLAG_NO_COLOR) && !p->color))
         return fail(c, SWR_ERR_BAD_ARG, "swr_render: colour/depth image pointer is NULL");
     int rc;
     if ((rc = swr_scene_upload(c, p->vertices, p->vertex_count, p->indices, p->index_count))) return rc;
     if ((rc = swr_target_set(c, p->width, p->height, 0, p->height))) return rc;
-    if ((rc = swr_draw(c, p->transform, p->flags))) return rc;
+    if ((rc = swr_draw_primitives(c, p->transform, p->flags, p->primitive_type))) return rc;
     if (!(p->flags & SWR_FLAG_NO_COLOR) && (rc = swr_read_color(c, p->color))) return rc;
     return swr_read_depth(c, p->depth);
 }

@@ -104,5 +104,6 @@ void launch_scan(const DeviceFrame& f, hipStream_t s);
 void launch_fill(const DeviceFrame& f, hipStream_t s);
 void launch_sort_bins(const DeviceFrame& f, hipStream_t s);
 void launch_raster(const DeviceFrame& f, hipStream_t s);
+void launch_points_or_lines(const DeviceFrame& f, int primitive_type, hipStream_t s);
 
 }  // namespace swr

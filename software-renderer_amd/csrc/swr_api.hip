@@ -32,7 +32,7 @@ struct swr_context {
     std::string err;
 
     // scene (RenderPass.vertices / .indices)
-    DevBuf vertices, indices, xyz, rgb, idx32, geo, geo_full, col;
+    DevBuf vertices, indices, xyz, rgb, idx32, geo, geo_full;
     int64_t nv = 0, ni = 0;
     bool has_scene = false;
 
@@ -122,7 +122,6 @@ DeviceFrame make_frame(swr_context* c, const float m[16], uint32_t flags) {
     f.ntri = c->ni / 3;
     f.geo = (GeomRec*)c->geo.p;
     f.geo_full = (GeomFull*)c->geo_full.p;
-    f.col = (ColRec*)c->col.p;
     uint32_t* tb = (uint32_t*)c->tilebuf.p;
     f.counters = tb;
     f.host_counters = c->h_counters_dev;
@@ -269,7 +268,7 @@ void swr_context_destroy(swr_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->xyz, &c->rgb, &c->idx32, &c->geo, &c->geo_full, &c->col, &c->color, &c->depth, &c->tilebuf,
+    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->xyz, &c->rgb, &c->idx32, &c->geo, &c->geo_full, &c->color, &c->depth, &c->tilebuf,
                       &c->ranges, &c->bins, &c->bin_matrix};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     if (c->h_counters) hipHostFree(c->h_counters);
@@ -299,7 +298,6 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     if ((rc = ensure(c, c->idx32, (size_t)index_count * 4))) return rc;
     if ((rc = ensure(c, c->geo, (size_t)(index_count / 3) * sizeof(GeomRec)))) return rc;
     if ((rc = ensure(c, c->geo_full, (size_t)(index_count / 3) * sizeof(GeomFull)))) return rc;
-    if ((rc = ensure(c, c->col, (size_t)(index_count / 3) * sizeof(ColRec)))) return rc;
     if ((rc = ensure(c, c->ranges, (size_t)(index_count / 3) * sizeof(uint2)))) return rc;
     if ((rc = ensure(c, c->tilebuf, (size_t)(CNT_WORDS + 3 * std::max(1, tiles_of(c->tg)) + 1) * 4))) return rc;
     if (vertex_count)

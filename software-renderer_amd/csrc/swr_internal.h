@@ -40,13 +40,6 @@ enum : uint32_t {
     GEOM_ORD_SHIFT = 2             // 3 x 2 bits: which of a,b,c is S0,S1,S2 of the y-sorted list (:271)
 };
 
-// Colour-mode side record for the resolve pass: vertex colours of a,b,c (w unused) + T(). 64 bytes.
-struct ColRec {
-    float4 a, b, c;
-    float4 tinv;                   // t00, t01, t10, t11
-};
-static_assert(sizeof(ColRec) == 64, "ColRec must be 64 bytes");
-
 struct Target {
     int32_t width, height;         // full framebuffer
     int32_t row_begin, row_end;    // band owned by this context
@@ -77,7 +70,6 @@ struct DeviceFrame {
     int64_t ntri;
     GeomRec* geo;
     GeomFull* geo_full;
-    ColRec* col;
     uint32_t* tile_count;          // [tiles] (triangle,tile) pairs per tile
     uint32_t* tile_start;          // [tiles+1] exclusive scan of tile_count
     uint32_t* counters;            // [CNT_WORDS]

@@ -2,7 +2,7 @@
 //
 // Pipeline of one frame (all on one stream, no host round trip):
 //   k_setup_hist  1 lane / triangle : vertex_shader x3, /w, screen map, truncation, y-sort,
-//                                     T() = inverse 2x2, 64-B GeomRec (+48-B ColRec); bbox -> tile
+//                                     validity via T(), 32-B GeomRec; bbox -> tile
 //                                     rectangle (8 B/triangle); per-workgroup tile histogram in LDS
 //   k_colscan     16 tiles / block  : prefix of the (workgroup x tile) count matrix over workgroups
 //   k_scan        1 workgroup       : exclusive scan of the per-tile totals
@@ -155,7 +155,6 @@ struct SetupArgs {
     int64_t ntri;
     GeomRec* geo;
     GeomFull* geo_full;
-    ColRec* col;            // may be null (depth-only)
     uint32_t* tile_count;
     uint2* ranges;
     Target tg;
@@ -198,7 +197,7 @@ __device__ __forceinline__ void decode_vertices(const GeomFull* __restrict__ ful
 }
 
 // Per-triangle work of the setup stage: the three vertex_shader calls, /w, screen map,
-// truncation, y-sort, T(); writes the 64-B GeomRec (+ ColRec) and returns the triangle's bbox
+// truncation, y-sort, T(); writes the 32-B GeomRec and returns the triangle's bbox
 // clipped to the band, in pixels: x = x0 | x1 << 16, y = (y0 - row_begin) | (y1 - row_begin) << 16
 // (RANGE_NONE_X when the bbox misses the band).
 __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
@@ -209,8 +208,9 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
     const uint32_t i1 = a.idx32[3 * p + 1];
     const uint32_t i2 = a.idx32[3 * p + 2];
     const float4 xa = a.xyz[i0], xb = a.xyz[i1], xc = a.xyz[i2];
-    float4 ca = make_float4(0, 0, 0, 0), cb = ca, cc = ca;
-    if (a.col) { ca = a.rgb[i0]; cb = a.rgb[i1]; cc = a.rgb[i2]; }   // colours are only needed for the ColRec
+    // vertex colours are passed through by vertex_shader untouched (Shaders.metal:53) and are only
+    // consumed by the resolve, which fetches them for the winning primitive through idx32 / rgb
+    const float4 ca = make_float4(0, 0, 0, 0), cb = ca, cc = ca;
 
     const float fw = (float)a.tg.width, fh = (float)a.tg.height;
     float sx[3], sy[3], sz[3];
@@ -262,7 +262,7 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
                            ((uint32_t)o0 << GEOM_ORD_SHIFT) | ((uint32_t)o1 << (GEOM_ORD_SHIFT + 2)) |
                            ((uint32_t)o2 << (GEOM_ORD_SHIFT + 4));
 
-    // record stores: 2 x 16 B per lane (+ 2 for the rare non-small triangle, + 4 in colour mode)
+    // record stores: 2 x 16 B per lane (+ 2 for the rare non-small triangle)
     {
         const uint32_t db = ((uint32_t)(ix[1] - ix[0]) & 0xFFFFu) | ((uint32_t)(iy[1] - iy[0]) << 16);
         const uint32_t dc = ((uint32_t)(ix[2] - ix[0]) & 0xFFFFu) | ((uint32_t)(iy[2] - iy[0]) << 16);
@@ -273,11 +273,6 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
             int4* fp = reinterpret_cast<int4*>(a.geo_full + p);
             fp[0] = make_int4(ix[0], iy[0], ix[1], iy[1]);
             fp[1] = make_int4(ix[2], iy[2], 0, 0);
-        }
-        if (a.col) {
-            float4* cp = reinterpret_cast<float4*>(a.col + p);
-            cp[0] = ca; cp[1] = cb; cp[2] = cc;
-            cp[3] = make_float4(t00, t01, t10, t11);
         }
     }
     // bbox ∩ band -> tiles.  Every covered pixel lies in [minx,maxx] x [S0.y,S2.y] (spans are
@@ -549,7 +544,8 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_bins(uint32_t* __restrict
 struct RasterArgs {
     const GeomRec* geo;
     const GeomFull* geo_full;
-    const ColRec* col;
+    const float4* rgb;          // [nv] vertex colours
+    const uint32_t* idx32;      // [3*ntri]
     const uint32_t* tile_start;
     const uint32_t* bins;
     const uint32_t* counters;
@@ -901,6 +897,11 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
         if (y > Y1 || x > X1) continue;
         uint32_t cpix[4];
         float dpix[4];
+        // neighbouring pixels usually share the winning primitive: its record, T() and vertex
+        // colours are fetched / computed once per run of equal primitives
+        uint32_t cached_prim = 0xFFFFFFFFu;
+        float4 q2 = make_float4(0, 0, 0, 0), q3 = q2, ca = q2, cb = q2, cc = q2;
+        float cfx = 0.0f, cfy = 0.0f;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const unsigned long long key = keys[ly * TILE_W + lx + k];
@@ -915,14 +916,22 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
                     need_rec = need_rec || (d == 0.0f);   // sign of zero comes from the winner
                 }
                 if (need_rec) {
-                    int4 g0; float4 q3;
-                    int vx[3], vy[3];
-                    load_vertices(a.geo, a.geo_full, prim, g0, q3, vx, vy);
-                    float4 q2;   // T(): from the colour record when there is one, else recomputed
-                    const float4* cp = reinterpret_cast<const float4*>(a.col + prim);
-                    if (want_color) q2 = cp[3];
-                    else tinv_of(vx[0], vy[0], vx[1], vy[1], vx[2], vy[2], q2.x, q2.y, q2.z, q2.w);
-                    const float cfx = (float)vx[2] + 0.5f, cfy = (float)vy[2] + 0.5f;
+                    if (prim != cached_prim) {
+                        cached_prim = prim;
+                        int4 g0;
+                        int vx[3], vy[3];
+                        load_vertices(a.geo, a.geo_full, prim, g0, q3, vx, vy);
+                        // T() of the winning primitive, recomputed (same expressions, same bits)
+                        tinv_of(vx[0], vy[0], vx[1], vy[1], vx[2], vy[2], q2.x, q2.y, q2.z, q2.w);
+                        cfx = (float)vx[2] + 0.5f;
+                        cfy = (float)vy[2] + 0.5f;
+                        if (want_color) {
+                            // vertex colours of a,b,c through the index buffer (RenderPass.indices / .vertices)
+                            ca = a.rgb[a.idx32[3 * (size_t)prim + 0]];
+                            cb = a.rgb[a.idx32[3 * (size_t)prim + 1]];
+                            cc = a.rgb[a.idx32[3 * (size_t)prim + 2]];
+                        }
+                    }
                     const float dx = ((float)(x + k) + 0.5f) - cfx;
                     const float dy = ((float)y + 0.5f) - cfy;
                     const float w0 = q2.x * dx + q2.y * dy;
@@ -930,7 +939,6 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
                     const float w2 = 1.0f - w0 - w1;
                     if (ZTEST) d = q3.x * w0 + q3.y * w1 + q3.z * w2;
                     if (want_color) {
-                        const float4 ca = cp[0], cb = cp[1], cc = cp[2];
                         VertexOut vin;
                         vin.pos = make_float4((float)(x + k) + 0.5f, (float)y + 0.5f, d, 1.0f);
                         vin.color = make_float3(ca.x * w0 + cb.x * w1 + cc.x * w2,     // :266
@@ -1052,7 +1060,7 @@ void launch_validate_indices(const int64_t* indices, int64_t count, int64_t vert
 static SetupArgs make_setup_args(const DeviceFrame& f) {
     SetupArgs a;
     a.xyz = f.xyz; a.rgb = f.rgb; a.idx32 = f.idx32; a.ntri = f.ntri;
-    a.geo = f.geo; a.geo_full = f.geo_full; a.col = (f.flags & SWR_FLAG_NO_COLOR) ? nullptr : f.col;
+    a.geo = f.geo; a.geo_full = f.geo_full;
     a.tile_count = f.tile_count; a.ranges = f.ranges; a.tg = f.tg;
     for (int c = 0; c < 4; c++)
         a.m.columns[c] = make_float4(f.m[4 * c + 0], f.m[4 * c + 1], f.m[4 * c + 2], f.m[4 * c + 3]);
@@ -1134,7 +1142,8 @@ void launch_sort_bins(const DeviceFrame& f, hipStream_t s) {
 
 void launch_raster(const DeviceFrame& f, hipStream_t s) {
     RasterArgs a;
-    a.geo = f.geo; a.geo_full = f.geo_full; a.col = f.col; a.tile_start = f.tile_start; a.bins = f.bins;
+    a.geo = f.geo; a.geo_full = f.geo_full; a.rgb = f.rgb; a.idx32 = f.idx32;
+    a.tile_start = f.tile_start; a.bins = f.bins;
     a.counters = f.counters; a.capacity = f.capacity;
     a.color = (f.flags & SWR_FLAG_NO_COLOR) ? nullptr : f.color;
     a.depth = f.depth; a.tg = f.tg;

@@ -289,7 +289,7 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
 // of rows of the triangle inside the tile minus one (0..31), or CLASS_BIG when its clipped bbox
 // area exceeds BIG_AREA.  k_raster counting-sorts its bin by this key so that the 64 triangles a
 // wave walks together have the same height.
-constexpr int BIG_AREA = 384;   // clipped bbox area above which a triangle is walked by the whole wave
+constexpr int BIG_AREA = 1 << 20;   // clipped bbox area above which a triangle is walked by the whole wave (never: the dense path handles any span)
 constexpr uint32_t CLASS_SHIFT = 26;
 constexpr uint32_t CLASS_BIG = 32;
 constexpr int NUM_CLASSES = 33;
@@ -692,8 +692,16 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
     uint32_t prim_pre = 0u;
     int4 q0_pre = make_int4(0, 0, 0, 0);
     float4 q1_pre = make_float4(0, 0, 0, 0);
-    if ((uint32_t)tid < m && VAR != 9 && VAR != 11) {
-        prim_pre = a.bins[b0 + tid];
+    // A batch of cnt <= 256 sorted entries goes to the waves in contiguous chunks: 64 per wave when
+    // the grid saturates the chip (fewest row steps in total), cnt/4 per wave when it does not
+    // (small scenes: shortest critical path).  Either way a wave sees a narrow range of sizes.
+    const bool spread = gridDim.x <= 1536;   // fewer tiles than the chip holds workgroups (256 CUs x 6)
+    const uint32_t cnt0 = min(m, (uint32_t)RASTER_THREADS);
+    const uint32_t per0 = spread ? (cnt0 + RASTER_THREADS / 64 - 1) / (RASTER_THREADS / 64) : 64u;
+    const uint32_t slot0 = (uint32_t)(tid >> 6) * per0 + (uint32_t)lane;
+    const bool have0 = (uint32_t)lane < per0 && slot0 < cnt0;
+    if (have0 && VAR != 9 && VAR != 11) {
+        prim_pre = a.bins[b0 + slot0];
         q0_pre = reinterpret_cast<const int4*>(a.geo + prim_pre)[0];
         q1_pre = reinterpret_cast<const float4*>(a.geo + prim_pre)[1];
     }
@@ -705,8 +713,11 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
     __syncthreads();
 
     for (uint32_t base0 = 0; VAR != 9 && VAR != 11 && base0 < m; base0 += RASTER_THREADS) {
-        const uint32_t e = base0 + tid;
-        const bool have = e < m;
+        const uint32_t cnt = min(m - base0, (uint32_t)RASTER_THREADS);
+        const uint32_t per = spread ? (cnt + RASTER_THREADS / 64 - 1) / (RASTER_THREADS / 64) : 64u;
+        const uint32_t slot = (uint32_t)(tid >> 6) * per + (uint32_t)lane;
+        const bool have = (uint32_t)lane < per && slot < cnt;
+        const uint32_t e = base0 + slot;
         TriState t;
         int ya = 1, yb = 0, bxa = 0, bxb = -1;
         bool big = false;

@@ -305,6 +305,35 @@ __device__ __forceinline__ uint32_t size_class(const PixBox& b, int tx, int ty) 
     return rows * cols > BIG_AREA ? CLASS_BIG : (uint32_t)(rows - 1);
 }
 
+// Visit every tile of a triangle's tile rectangle.  Rectangles of up to COOP_TILES tiles are walked
+// by the owning lane; larger ones (big triangles) are walked by the whole wave, one rectangle at a
+// time, lanes striding over its tiles — a full-screen triangle would otherwise keep one lane busy
+// for thousands of iterations.  Must be called by all 64 lanes of the wave (b.x0 > b.x1 = no tiles).
+constexpr int COOP_TILES = 8;
+template <class F>
+__device__ __forceinline__ void for_each_tile(const PixBox& b, uint32_t p, F&& fn) {
+    const bool any = b.x0 <= b.x1;
+    const int tx0 = b.x0 / TILE_W, ty0 = b.y0 / TILE_H;
+    const int ntx = any ? b.x1 / TILE_W - tx0 + 1 : 0, nty = any ? b.y1 / TILE_H - ty0 + 1 : 0;
+    const int n = ntx * nty;
+    if (n > 0 && n <= COOP_TILES)
+        for (int ty = ty0; ty < ty0 + nty; ty++)
+            for (int tx = tx0; tx < tx0 + ntx; tx++) fn(b, p, tx, ty);
+    unsigned long long mask = __ballot(n > COOP_TILES);
+    const int lane = threadIdx.x & 63;
+    while (mask) {
+        const int src = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)mask) - 1);
+        mask &= mask - 1;
+        PixBox sb;
+        sb.x0 = __builtin_amdgcn_readlane(b.x0, src); sb.x1 = __builtin_amdgcn_readlane(b.x1, src);
+        sb.y0 = __builtin_amdgcn_readlane(b.y0, src); sb.y1 = __builtin_amdgcn_readlane(b.y1, src);
+        const uint32_t sp = (uint32_t)__builtin_amdgcn_readlane((int)p, src);
+        const int stx0 = sb.x0 / TILE_W, sty0 = sb.y0 / TILE_H;
+        const int sntx = sb.x1 / TILE_W - stx0 + 1, sn = sntx * (sb.y1 / TILE_H - sty0 + 1);
+        for (int k = lane; k < sn; k += 64) fn(sb, sp, stx0 + k % sntx, sty0 + k / sntx);
+    }
+}
+
 // ---- binning, LDS path (default): no global atomics ------------------------------------------
 // Workgroup g owns the contiguous chunk [g*chunk, (g+1)*chunk) of the primitives in BOTH walks.
 // k_setup_hist: per-workgroup tile histogram in LDS (ds_add), written as row g of the matrix
@@ -318,14 +347,17 @@ __global__ __launch_bounds__(1024) void k_setup_hist(SetupArgs a, uint32_t* __re
     __syncthreads();
     const int64_t p0 = (int64_t)blockIdx.x * chunk;
     const int64_t p1 = min(p0 + (int64_t)chunk, a.ntri);
-    for (int64_t p = p0 + threadIdx.x; p < p1; p += blockDim.x) {
-        const uint2 r = setup_triangle(a, p);
-        a.ranges[p] = r;
-        const PixBox b = unpack_box(r);
-        if (b.x0 <= b.x1)
-            for (int ty = b.y0 / TILE_H; ty <= b.y1 / TILE_H; ty++)
-                for (int tx = b.x0 / TILE_W; tx <= b.x1 / TILE_W; tx++)
-                    atomicAdd(&hist[ty * a.tg.tiles_x + tx], 1u);
+    const int tiles_x = a.tg.tiles_x;
+    for (int64_t pw = p0; pw < p1; pw += blockDim.x) {          // wave-uniform trip count
+        const int64_t p = pw + threadIdx.x;
+        uint2 r = make_uint2(RANGE_NONE_X, 0u);
+        if (p < p1) {
+            r = setup_triangle(a, p);
+            a.ranges[p] = r;
+        }
+        for_each_tile(unpack_box(r), (uint32_t)p, [&](const PixBox&, uint32_t, int tx, int ty) {
+            atomicAdd(&hist[ty * tiles_x + tx], 1u);
+        });
     }
     __syncthreads();
     uint32_t* row = M + (size_t)blockIdx.x * (size_t)ntiles;
@@ -409,14 +441,13 @@ __global__ __launch_bounds__(1024) void k_fill_lds(const uint2* __restrict__ ran
     __syncthreads();
     const int64_t p0 = (int64_t)blockIdx.x * chunk;
     const int64_t p1 = min(p0 + (int64_t)chunk, ntri);
-    for (int64_t p = p0 + t; p < p1; p += 1024) {
-        const PixBox b = unpack_box(ranges[p]);
-        if (b.x0 > b.x1) continue;
-        for (int ty = b.y0 / TILE_H; ty <= b.y1 / TILE_H; ty++)
-            for (int tx = b.x0 / TILE_W; tx <= b.x1 / TILE_W; tx++) {
-                const uint32_t pos = atomicAdd(&cursor[ty * tiles_x + tx], 1u);
-                bins[pos] = (uint32_t)p | (tag_class ? size_class(b, tx, ty) << CLASS_SHIFT : 0u);
-            }
+    for (int64_t pw = p0; pw < p1; pw += 1024) {                // wave-uniform trip count
+        const int64_t p = pw + t;
+        const uint2 r = p < p1 ? ranges[p] : make_uint2(RANGE_NONE_X, 0u);
+        for_each_tile(unpack_box(r), (uint32_t)p, [&](const PixBox& b, uint32_t prim, int tx, int ty) {
+            const uint32_t pos = atomicAdd(&cursor[ty * tiles_x + tx], 1u);
+            bins[pos] = prim | (tag_class ? size_class(b, tx, ty) << CLASS_SHIFT : 0u);
+        });
     }
 }
 

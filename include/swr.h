@@ -51,8 +51,14 @@ enum {
     SWR_FLAG_DEPTH_TEST = 1u << 0, /* restore Renderer.swift:257-261: depth = za*w0+zb*w1+zc*w2,
                                       strict '<', first-drawn wins ties (also :344-348,
                                       Shaders.metal:158-165) */
-    SWR_FLAG_NO_COLOR   = 1u << 1  /* depth-only pass: the colour image is neither cleared nor
+    SWR_FLAG_NO_COLOR   = 1u << 1, /* depth-only pass: the colour image is neither cleared nor
                                       written (BASELINE config 4) */
+    SWR_FLAG_METAL_RULES = 1u << 2 /* the Metal path's rules instead of the CPU renderer's:
+                                      vertices snapped with round() (Shaders.metal:71), one thread per ROI
+                                      pixel with inside = all(0 <= ws <= 1) (:133-153), z-test always on
+                                      (:158-161), bgra8Unorm store (round to nearest), ROIs whose min-x or
+                                      min-y is 0 skipped (GpuRenderer.swift:122-124); IEEE arithmetic (the
+                                      reference's MTL_FAST_MATH build is not bit-reproducible) */
 };
 
 /* ---- Vertex (Renderer.swift:154-157): two SIMD3<Float>, each padded to 16 B --------- */

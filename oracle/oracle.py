@@ -50,6 +50,8 @@ def lib():
                                              ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64,
                                              ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_int64,
                                              ctypes.c_int64, ctypes.POINTER(Stats)]
+        L.swro_render_metal.restype = ctypes.c_int
+        L.swro_render_metal.argtypes = L.swro_render.argtypes
         L.swro_interpolate.restype = ctypes.c_int64
         L.swro_interpolate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]
         L.swro_quantise.restype = ctypes.c_uint8
@@ -77,6 +79,26 @@ def render(vertices: np.ndarray, indices: np.ndarray, transform: np.ndarray, wid
                                   width, height, v.ctypes.data, v.shape[0] if v.ndim == 2 else v.size // 8,
                                   i.ctypes.data, i.size, m.ctypes.data, flags, primitive_type, row_begin, row_end,
                                   ctypes.byref(st))
+    return color, depth, st, rc
+
+
+def render_metal(vertices, indices, transform, width: int, height: int, flags: int = 0,
+                 row_begin: int = 0, row_end: int | None = None, color=None, depth=None):
+    """The Metal path's rules (Shaders.metal / GpuRenderer.swift) in IEEE arithmetic."""
+    L = lib()
+    v = np.ascontiguousarray(vertices, dtype=np.float32)
+    i = np.ascontiguousarray(indices, dtype=np.int64)
+    m = np.ascontiguousarray(transform, dtype=np.float32)
+    if row_end is None:
+        row_end = height
+    if color is None and not (flags & NO_COLOR):
+        color = np.full((height, width, 4), 0xCD, dtype=np.uint8)
+    if depth is None:
+        depth = np.full((height, width), -123.0, dtype=np.float32)
+    st = Stats()
+    rc = L.swro_render_metal(color.ctypes.data if color is not None else None, depth.ctypes.data, width, height,
+                             v.ctypes.data, v.shape[0] if v.ndim == 2 else v.size // 8, i.ctypes.data, i.size,
+                             m.ctypes.data, flags, row_begin, row_end, ctypes.byref(st))
     return color, depth, st, rc
 
 

@@ -283,3 +283,96 @@ int swro_render_primitives(uint8_t* color, float* depth, int64_t W, int64_t H,
     if (stats) *stats = st;
     return 0;
 }
+
+/* ---- the Metal path's rules (Shaders.metal / GpuRenderer.swift), see swr_oracle.h ------------- */
+static uint8_t unorm8(float v) {            /* bgra8Unorm store: clamp, *255, round to nearest even */
+    float c = fminf(fmaxf(v, 0.0f), 1.0f);
+    return (uint8_t)rintf(c * 255.0f);
+}
+
+int swro_render_metal(uint8_t* color, float* depth, int64_t W, int64_t H,
+                      const swro_vertex* vertices, int64_t vertex_count,
+                      const int64_t* indices, int64_t index_count,
+                      const float M[16], uint32_t flags,
+                      int64_t row_begin, int64_t row_end, swro_stats* stats) {
+    if (!depth || W <= 0 || H <= 0 || !M) return -1;
+    if (!(flags & SWRO_NO_COLOR) && !color) return -1;
+    if (index_count < 0 || vertex_count < 0) return -1;
+    if (index_count > 0 && (!indices || !vertices)) return -1;
+    if (index_count % 3 != 0) return -2;
+    if (row_begin < 0 || row_end > H || row_begin > row_end) return -1;
+    for (int64_t i = 0; i < index_count; i++)
+        if (indices[i] < 0 || indices[i] >= vertex_count) return -3;
+    swro_stats st;
+    memset(&st, 0, sizeof st);
+    /* clear_depth_buffer (Shaders.metal:33-37) + colour clear (GpuRenderer.swift:78) */
+    if (!(flags & SWRO_NO_COLOR))
+        memset(color + (size_t)row_begin * (size_t)W * 4, 0, (size_t)(row_end - row_begin) * (size_t)W * 4);
+    for (int64_t i = row_begin * W; i < row_end * W; i++) depth[i] = INFINITY;
+
+    const float fw = (float)W, fh = (float)H;
+    for (int64_t p = 0; p < index_count / 3; p++) {               /* serial dispatches, GpuRenderer.swift:117 */
+        float px[3], py[3], pz[3], col[3][3];
+        int ok = 1;
+        for (int k = 0; k < 3; k++) {
+            const swro_vertex* v = &vertices[indices[3 * p + k]];
+            float x = v->xyz[0], y = v->xyz[1], z = v->xyz[2];
+            float r[4];
+            for (int c = 0; c < 4; c++) {                         /* vertex_shader :50 */
+                float a = M[0 + c] * x;
+                a = a + M[4 + c] * y;
+                a = a + M[8 + c] * z;
+                a = a + M[12 + c] * 1.0f;
+                r[c] = a;
+            }
+            float nx = r[0] / r[3], ny = r[1] / r[3], nz = r[2] / r[3];   /* :68 */
+            float u = nx * 0.5f + 0.5f, w = ny * -0.5f + 0.5f;             /* :70 */
+            px[k] = roundf(u * fw);                                         /* :71 round = half away from zero */
+            py[k] = roundf(w * fh);
+            pz[k] = nz;
+            for (int c = 0; c < 3; c++) col[k][c] = v->color[c];
+            /* uint2(pos.xy) (:102-104): undefined for negative / non-finite -> skip (documented) */
+            if (!(px[k] >= 0.0f && px[k] < COORD_LIMIT) || !(py[k] >= 0.0f && py[k] < COORD_LIMIT)) ok = 0;
+        }
+        if (!ok) { st.triangles_skipped++; continue; }
+        int64_t ax = (int64_t)px[0], ay = (int64_t)py[0], bx = (int64_t)px[1], by = (int64_t)py[1];
+        int64_t cx = (int64_t)px[2], cy = (int64_t)py[2];
+        int64_t minx = ax < bx ? (ax < cx ? ax : cx) : (bx < cx ? bx : cx);
+        int64_t maxx = ax > bx ? (ax > cx ? ax : cx) : (bx > cx ? bx : cx);
+        int64_t miny = ay < by ? (ay < cy ? ay : cy) : (by < cy ? by : cy);
+        int64_t maxy = ay > by ? (ay > cy ? ay : cy) : (by > cy ? by : cy);
+        if (minx == 0 || miny == 0) { st.triangles_skipped++; continue; }   /* GpuRenderer.swift:122-124 */
+        st.triangles_drawn++;
+        /* rasterizer_pass :133-166, one "thread" per ROI pixel; texture bounds + band scissor */
+        const float p1x = px[0], p1y = py[0], p2x = px[1], p2y = py[1], p3x = px[2], p3y = py[2];
+        const float divider = (p1x - p3x) * (p2y - p3y) - (p2x - p3x) * (p1y - p3y);        /* :143 */
+        int64_t y0 = miny < row_begin ? row_begin : miny, y1 = maxy > row_end - 1 ? row_end - 1 : maxy;
+        int64_t x0 = minx, x1 = maxx > W - 1 ? W - 1 : maxx;
+        for (int64_t y = y0; y <= y1; y++)
+            for (int64_t x = x0; x <= x1; x++) {
+                const float sxp = (float)x + 0.5f, syp = (float)y + 0.5f;                    /* :133 */
+                float w0 = (p2y - p3y) * (sxp - p3x) + (p3x - p2x) * (syp - p3y);            /* :144 */
+                w0 = w0 / divider;                                                           /* :145 */
+                float w1 = (p3y - p1y) * (sxp - p3x) + (p1x - p3x) * (syp - p3y);            /* :147 */
+                w1 = w1 / divider;                                                           /* :148 */
+                const float w2 = 1.0f - w0 - w1;                                             /* :149 */
+                st.fragments++;
+                if (!(0.0f <= w0 && w0 <= 1.0f && 0.0f <= w1 && w1 <= 1.0f && 0.0f <= w2 && w2 <= 1.0f))
+                    continue;                                                                /* :153 */
+                const float z = w0 * pz[0] + w1 * pz[1] + w2 * pz[2];                        /* :157,159 */
+                const size_t at = (size_t)(y * W + x);
+                if (!(z < depth[at])) continue;                                              /* :161 */
+                st.fragments_written++;
+                if (!(flags & SWRO_NO_COLOR)) {
+                    float c[3];
+                    for (int ch = 0; ch < 3; ch++)                                           /* :162 */
+                        c[ch] = w0 * col[0][ch] + w1 * col[1][ch] + w2 * col[2][ch];
+                    uint8_t* q = color + at * 4;                                             /* :163 bgra8Unorm */
+                    q[0] = unorm8(c[2]); q[1] = unorm8(c[1]); q[2] = unorm8(c[0]); q[3] = unorm8(1.0f);
+                }
+                depth[at] = z;                                                               /* :164 */
+            }
+    }
+    if (stats) *stats = st;
+    return 0;
+}

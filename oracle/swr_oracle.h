@@ -66,6 +66,26 @@ int swro_render_primitives(uint8_t* color, float* depth, int64_t W, int64_t H,
                            const float transform[16], uint32_t flags, int32_t primitive_type,
                            int64_t row_begin, int64_t row_end, swro_stats* stats);
 
+/* The Metal path's rules (renderer/Shaders.metal:57-167 + renderer/GpuRenderer.swift:109-139) in IEEE
+ * arithmetic — SURVEY.md §A.3, §8(f) rank 1.  PARITY UNPINNED twice over: the reference compiles its
+ * shaders with MTL_FAST_MATH = YES (project.pbxproj:221,278), so the Metal binary is not
+ * bit-reproducible even against itself; this restates the source text with one IEEE op per operator.
+ *   vertex_pass   :57-75   pos = M*(xyz,1); pos.xyz /= pos.w; pos.xy = round(uv * screen)  (half away from 0)
+ *   roi_pass      :89-114  bbox of the uint-cast snapped vertices
+ *   host          GpuRenderer.swift:122-124  primitives whose ROI min-x or min-y is 0 are skipped
+ *   rasterizer    :123-167 one thread per bbox pixel, sample at +0.5; barycentrics by the `divider`
+ *                          formula; inside = all(0 <= ws <= 1); z = ws.pos.z; strict '<' z-test;
+ *                          colour = ws.colours through fragment_shader; bgra8Unorm store
+ * Documented choices: a negative / non-finite / >= 2^30 snapped coordinate (uint cast undefined in
+ * MSL) skips the primitive; bbox pixels outside the textures are dropped; float -> unorm8 is
+ * rint(clamp(v,0,1)*255) (round to nearest even, the MSL-preferred conversion).
+ * flags: SWRO_NO_COLOR honoured; the z-test is always on (it is in the shader). */
+int swro_render_metal(uint8_t* color, float* depth, int64_t W, int64_t H,
+                      const swro_vertex* vertices, int64_t vertex_count,
+                      const int64_t* indices, int64_t index_count,
+                      const float transform[16], uint32_t flags,
+                      int64_t row_begin, int64_t row_end, swro_stats* stats);
+
 /* Renderer.interpolate(values:t:) (Renderer.swift:467-494), exposed for unit tests.
  * pts = n (x,y) pairs, n in {2,3}. */
 int64_t swro_interpolate(const int64_t* pts_xy, int n, int64_t t);

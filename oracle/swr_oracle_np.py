@@ -122,3 +122,64 @@ def render(vertices, indices, transform, width, height, depth_test=False, no_col
                 row = color[y, x0:x1 + 1]
                 row[sel] = px[sel]
     return color, depth, skipped
+
+
+def render_metal(vertices, indices, transform, width, height, no_color=False):
+    """Independent NumPy restatement of the Metal path's rules (renderer/Shaders.metal:57-167,
+    renderer/GpuRenderer.swift:109-139) in IEEE float32 — see swr_oracle.h for the documented choices.
+    Vectorised over the ROI of each primitive."""
+    W, H = int(width), int(height)
+    color = np.zeros((H, W, 4), dtype=np.uint8)
+    depth = np.full((H, W), np.inf, dtype=F)
+    M = np.asarray(transform, dtype=F).reshape(4, 4)
+    V = np.asarray(vertices, dtype=F).reshape(-1, 8)
+    idx = np.asarray(indices, dtype=np.int64)
+    with np.errstate(all="ignore"):
+        for p in range(idx.size // 3):
+            P, Z, C = [], [], []
+            ok = True
+            for k in range(3):
+                v = V[idx[3 * p + k]]
+                r = M[0] * v[0]
+                r = r + M[1] * v[1]
+                r = r + M[2] * v[2]
+                r = r + M[3] * F(1.0)
+                n = r[:3] / r[3]                                         # Shaders.metal:68
+                uv = (n[0] * F(0.5) + F(0.5), n[1] * F(-0.5) + F(0.5))   # :70
+                px = np.trunc(uv[0] * F(W) + np.copysign(F(0.5), uv[0] * F(W)))   # round half away (:71)
+                py = np.trunc(uv[1] * F(H) + np.copysign(F(0.5), uv[1] * F(H)))
+                # (the +-0.5 trick is exact here: |value| < 2^23 in every test scene)
+                if not (0 <= px < 2.0 ** 30 and 0 <= py < 2.0 ** 30):
+                    ok = False
+                P.append((F(px), F(py)))
+                Z.append(n[2])
+                C.append(v[4:7].copy())
+            if not ok:
+                continue
+            xs = [int(q[0]) for q in P]
+            ys = [int(q[1]) for q in P]
+            if min(xs) == 0 or min(ys) == 0:                            # GpuRenderer.swift:122-124
+                continue
+            (p1x, p1y), (p2x, p2y), (p3x, p3y) = P
+            divider = (p1x - p3x) * (p2y - p3y) - (p2x - p3x) * (p1y - p3y)
+            x0, x1 = min(xs), min(max(xs), W - 1)
+            y0, y1 = min(ys), min(max(ys), H - 1)
+            if x0 > x1 or y0 > y1:
+                continue
+            gx = (np.arange(x0, x1 + 1).astype(F) + F(0.5))[None, :]
+            gy = (np.arange(y0, y1 + 1).astype(F) + F(0.5))[:, None]
+            w0 = ((p2y - p3y) * (gx - p3x) + (p3x - p2x) * (gy - p3y)) / divider
+            w1 = ((p3y - p1y) * (gx - p3x) + (p1x - p3x) * (gy - p3y)) / divider
+            w2 = F(1.0) - w0 - w1
+            inside = (w0 >= 0) & (w0 <= 1) & (w1 >= 0) & (w1 <= 1) & (w2 >= 0) & (w2 <= 1)
+            z = w0 * Z[0] + w1 * Z[1] + w2 * Z[2]
+            sub = depth[y0:y1 + 1, x0:x1 + 1]
+            win = inside & (z < sub)
+            sub[win] = z[win]
+            if not no_color:
+                rgb = [w0 * C[0][ch] + w1 * C[1][ch] + w2 * C[2][ch] for ch in range(3)]
+                un = lambda a: np.rint(np.fmin(np.fmax(a, F(0)), F(1)) * F(255)).astype(np.uint8)
+                px4 = np.stack([un(rgb[2]), un(rgb[1]), un(rgb[0]), np.full(z.shape, 255, np.uint8)], axis=-1)
+                csub = color[y0:y1 + 1, x0:x1 + 1]
+                csub[win] = px4[win]
+    return color, depth

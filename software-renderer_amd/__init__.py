@@ -11,6 +11,7 @@ hyphen) or through the `swr_amd` alias module at the repo root.
 from . import scenes  # noqa: F401
 from .binding import (  # noqa: F401
     FLAG_DEPTH_TEST,
+    FLAG_METAL_RULES,
     FLAG_NO_COLOR,
     Context,
     SwrError,

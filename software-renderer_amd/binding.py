@@ -12,6 +12,7 @@ _LIB = os.path.join(_PKG, "lib", "libswr_hip.so")
 
 FLAG_DEPTH_TEST = 1
 FLAG_NO_COLOR = 2
+FLAG_METAL_RULES = 4
 
 # every symbol include/swr.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [

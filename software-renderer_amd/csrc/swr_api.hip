@@ -363,7 +363,7 @@ int swr_draw_primitives(swr_context* c, const float transform[16], uint32_t flag
     }
     if (!c->has_scene || !c->has_target)
         return fail(c, SWR_ERR_NO_SCENE, "swr_draw needs swr_scene_upload and swr_target_set first");
-    if (flags & ~(uint32_t)(SWR_FLAG_DEPTH_TEST | SWR_FLAG_NO_COLOR))
+    if (flags & ~(uint32_t)(SWR_FLAG_DEPTH_TEST | SWR_FLAG_NO_COLOR | SWR_FLAG_METAL_RULES))
         return fail(c, SWR_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
     HIP_TRY(c, hipSetDevice(c->device));
     memcpy(c->last_m, transform, sizeof c->last_m);

@@ -159,6 +159,7 @@ struct SetupArgs {
     uint2* ranges;
     Target tg;
     float4x4 m;
+    int metal;              // SWR_FLAG_METAL_RULES: Shaders.metal / GpuRenderer.swift rules
 };
 
 constexpr uint32_t RANGE_NONE_X = 0x00000001u;   // tx0 = 1, tx1 = 0: empty rectangle
@@ -231,12 +232,20 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
             sx[k] = u * fw;
             sy[k] = v * fh;
             sz[k] = nz;
+            if (a.metal) {                      // vertex_pass: pixels = round(uv * screen) (Shaders.metal:71)
+                sx[k] = roundf(sx[k]);          // half away from zero, like Metal's round()
+                sy[k] = roundf(sy[k]);
+            }
         }
     }
     bool ok = true;
 #pragma unroll
     for (int k = 0; k < 3; k++)
         ok = ok && (fabsf(sx[k]) < COORD_LIMIT) && (fabsf(sy[k]) < COORD_LIMIT);
+    if (a.metal) {                              // uint2(pos.xy) (Shaders.metal:102-104): negative is undefined -> skip
+#pragma unroll
+        for (int k = 0; k < 3; k++) ok = ok && (sx[k] >= 0.0f) && (sy[k] >= 0.0f);
+    }
 
     int ix[3] = {0, 0, 0}, iy[3] = {0, 0, 0};
     if (ok) {
@@ -254,8 +263,16 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
         int t = o1; o1 = o2; o2 = t;
         if (sy[o1] < sy[o0]) { t = o0; o0 = o1; o1 = t; }
     }
-    const int s0y = iy[o0], s2y = iy[o2];
+    int s0y = iy[o0], s2y = iy[o2];
     const int minx = min(ix[0], min(ix[1], ix[2])), maxx = max(ix[0], max(ix[1], ix[2]));
+    if (a.metal) {
+        // roi_pass (Shaders.metal:89-114): the bbox of the snapped vertices; the host skips ROIs whose
+        // min-x or min-y is 0 (GpuRenderer.swift:122-124).  det == 0 here is the shader's `divider`
+        // (same products): it would make every weight inf/NaN, i.e. no pixel inside -> skip as well.
+        s0y = min(iy[0], min(iy[1], iy[2]));
+        s2y = max(iy[0], max(iy[1], iy[2]));
+        ok = ok && minx != 0 && s0y != 0;
+    }
     // int16 vertex deltas and 32-bit span arithmetic are exact when the bbox extents are < 2^15
     const bool small = ((int64_t)maxx - (int64_t)minx < 32768) && ((int64_t)s2y - (int64_t)s0y < 32768);
     const uint32_t flags = (ok ? GEOM_VALID : 0u) | (small ? GEOM_SMALL : 0u) |
@@ -1014,6 +1031,138 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------
+// k_raster_metal: the Metal path's rules (SWR_FLAG_METAL_RULES; Shaders.metal:123-167) on the same
+// binning, LDS key tiles and visibility keys.  One thread per pixel of the triangle's ROI (here:
+// ROI ∩ tile), sample at +0.5, barycentrics by the `divider` formula, inside = all(0 <= ws <= 1),
+// strict '<' z-test in primitive order (= min depth, ties -> lowest index), colour through
+// fragment_shader and a bgra8Unorm store.  First version: each wave takes one triangle at a time
+// (readlane broadcast) and spreads the ROI rows over its lanes in 16x4 / 32x2 / 64x1 chunks.
+// ------------------------------------------------------------------------------------------
+struct MetalTri {
+    float p3x, p3y, A0, B0, A1, B1, divider, z0, z1, z2;
+};
+__device__ __forceinline__ void metal_consts(const int vx[3], const int vy[3], float za, float zb, float zc,
+                                             MetalTri& m) {
+    const float p1x = (float)vx[0], p1y = (float)vy[0], p2x = (float)vx[1], p2y = (float)vy[1];
+    m.p3x = (float)vx[2]; m.p3y = (float)vy[2];
+    m.divider = (p1x - m.p3x) * (p2y - m.p3y) - (p2x - m.p3x) * (p1y - m.p3y);   // :143
+    m.A0 = p2y - m.p3y; m.B0 = m.p3x - p2x;                                       // :144
+    m.A1 = m.p3y - p1y; m.B1 = p1x - m.p3x;                                       // :147
+    m.z0 = za; m.z1 = zb; m.z2 = zc;
+}
+__device__ __forceinline__ bool metal_weights(const MetalTri& m, int x, int y, float& w0, float& w1, float& w2) {
+    const float sx = (float)x + 0.5f, sy = (float)y + 0.5f;                       // :133
+    w0 = m.A0 * (sx - m.p3x) + m.B0 * (sy - m.p3y);
+    w0 = w0 / m.divider;                                                          // :145
+    w1 = m.A1 * (sx - m.p3x) + m.B1 * (sy - m.p3y);
+    w1 = w1 / m.divider;                                                          // :148
+    w2 = 1.0f - w0 - w1;                                                          // :149
+    return 0.0f <= w0 && w0 <= 1.0f && 0.0f <= w1 && w1 <= 1.0f && 0.0f <= w2 && w2 <= 1.0f;   // :153
+}
+
+__global__ __launch_bounds__(RASTER_THREADS) void k_raster_metal(RasterArgs a) {
+    __shared__ unsigned long long keys[TILE_W * TILE_H];
+    const int tile = blockIdx.x;
+    const int tx = tile % a.tg.tiles_x, ty = tile / a.tg.tiles_x;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int X0 = tx * TILE_W, Y0 = a.tg.row_begin + ty * TILE_H;
+    const int X1 = min(X0 + TILE_W, a.tg.width) - 1;
+    const int Y1 = min(Y0 + TILE_H, a.tg.row_end) - 1;
+    for (int i = tid; i < TILE_W * TILE_H; i += RASTER_THREADS) keys[i] = KEY_EMPTY;   // fused clear
+    __syncthreads();
+    const bool overflow = a.counters[CNT_PAIRS] > a.capacity;
+    const uint32_t b0 = overflow ? 0u : a.tile_start[tile];
+    const uint32_t b1 = overflow ? 0u : a.tile_start[tile + 1];
+    const uint32_t m = b1 - b0;
+    for (uint32_t base0 = 0; base0 < m; base0 += RASTER_THREADS) {
+        const uint32_t e = base0 + tid;
+        const bool have = e < m;
+        int vx[3] = {0, 0, 0}, vy[3] = {0, 0, 0};
+        float za = 0, zb = 0, zc = 0;
+        uint32_t prim = 0;
+        if (have) {
+            prim = a.bins[b0 + e];
+            int4 q0; float4 q1;
+            load_vertices(a.geo, a.geo_full, prim, q0, q1, vx, vy);
+            za = q1.x; zb = q1.y; zc = q1.z;
+        }
+        unsigned long long todo = __ballot(have);
+        while (todo) {
+            const int src = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)todo) - 1);
+            todo &= todo - 1;
+            int ux[3], uy[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) { ux[k] = bcast_i(vx[k], src); uy[k] = bcast_i(vy[k], src); }
+            MetalTri mt;
+            metal_consts(ux, uy, bcast_f(za, src), bcast_f(zb, src), bcast_f(zc, src), mt);
+            const uint32_t uprim = (uint32_t)bcast_i((int)prim, src);
+            const int xa = max(min(ux[0], min(ux[1], ux[2])), X0), xb = min(max(ux[0], max(ux[1], ux[2])), X1);
+            const int ya = max(min(uy[0], min(uy[1], uy[2])), Y0), yb = min(max(uy[0], max(uy[1], uy[2])), Y1);
+            if (xa > xb || ya > yb) continue;
+            const int w = xb - xa + 1;
+            const int lw = w <= 16 ? 4 : (w <= 32 ? 5 : 6);
+            const int cw = 1 << lw, rows_per = 64 >> lw;
+            for (int yr = ya; yr <= yb; yr += rows_per) {
+                const int y = yr + (lane >> lw);
+                for (int x = xa + (lane & (cw - 1)); x <= xb; x += cw) {
+                    float w0, w1, w2;
+                    if (y <= yb && metal_weights(mt, x, y, w0, w1, w2)) {
+                        float z = w0 * mt.z0 + w1 * mt.z1 + w2 * mt.z2;                   // :157,:159
+                        if (z < INFINITY) {                                               // can pass :161 at all
+                            z = z + 0.0f;
+                            atomicMin(&keys[(y - Y0) * TILE_W + (x - X0)],
+                                      ((unsigned long long)orderable_depth(z) << 32) | (unsigned long long)uprim);
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    // resolve: winner -> same weights -> z, colour (fragment_shader) -> bgra8Unorm (round to nearest even)
+    const bool want_color = a.color != nullptr;
+    const int W = a.tg.width;
+    for (int i = tid; i < TILE_W * TILE_H; i += RASTER_THREADS) {
+        const int ly = i / TILE_W, lx = i % TILE_W;
+        const int y = Y0 + ly, x = X0 + lx;
+        if (y > Y1 || x > X1) continue;
+        const unsigned long long key = keys[i];
+        uint32_t c = 0u;
+        float d = INFINITY;
+        if (key != KEY_EMPTY) {
+            const uint32_t prim = (uint32_t)key;
+            int4 q0; float4 q1;
+            int vx[3], vy[3];
+            load_vertices(a.geo, a.geo_full, prim, q0, q1, vx, vy);
+            MetalTri mt;
+            metal_consts(vx, vy, q1.x, q1.y, q1.z, mt);
+            float w0, w1, w2;
+            metal_weights(mt, x, y, w0, w1, w2);
+            d = w0 * mt.z0 + w1 * mt.z1 + w2 * mt.z2;
+            if (want_color) {
+                const float4 ca = a.rgb[a.idx32[3 * (size_t)prim + 0]];
+                const float4 cb = a.rgb[a.idx32[3 * (size_t)prim + 1]];
+                const float4 cc = a.rgb[a.idx32[3 * (size_t)prim + 2]];
+                VertexOut vin;
+                vin.pos = make_float4((float)x + 0.5f, (float)y + 0.5f, d, 1.0f);
+                vin.color = make_float3(w0 * ca.x + w1 * cb.x + w2 * cc.x,              // :162
+                                        w0 * ca.y + w1 * cb.y + w2 * cc.y,
+                                        w0 * ca.z + w1 * cb.z + w2 * cc.z);
+                const float4 f = fragment_shader(vin);                                    // :163
+                const uint32_t qb = (uint32_t)rintf(fminf(fmaxf(f.z, 0.0f), 1.0f) * 255.0f);
+                const uint32_t qg = (uint32_t)rintf(fminf(fmaxf(f.y, 0.0f), 1.0f) * 255.0f);
+                const uint32_t qr = (uint32_t)rintf(fminf(fmaxf(f.x, 0.0f), 1.0f) * 255.0f);
+                const uint32_t qa = (uint32_t)rintf(fminf(fmaxf(f.w, 0.0f), 1.0f) * 255.0f);
+                c = qb | (qg << 8) | (qr << 16) | (qa << 24);
+            }
+        }
+        const size_t at = (size_t)(y - a.tg.row_begin) * (size_t)W + (size_t)x;
+        if (want_color) reinterpret_cast<uint32_t*>(a.color)[at] = c;
+        a.depth[at] = d;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // PrimitiveType .vertices (Renderer.swift:295-302) and .line (empty stub, :289-293)
 // ------------------------------------------------------------------------------------------
 // .vertices plots every transformed vertex reference at (Int(sx), Int(sy)) with its own colour, in
@@ -1104,6 +1253,7 @@ static SetupArgs make_setup_args(const DeviceFrame& f) {
     a.xyz = f.xyz; a.rgb = f.rgb; a.idx32 = f.idx32; a.ntri = f.ntri;
     a.geo = f.geo; a.geo_full = f.geo_full;
     a.tile_count = f.tile_count; a.ranges = f.ranges; a.tg = f.tg;
+    a.metal = (f.flags & SWR_FLAG_METAL_RULES) ? 1 : 0;
     for (int c = 0; c < 4; c++)
         a.m.columns[c] = make_float4(f.m[4 * c + 0], f.m[4 * c + 1], f.m[4 * c + 2], f.m[4 * c + 3]);
     return a;
@@ -1192,6 +1342,10 @@ void launch_raster(const DeviceFrame& f, hipStream_t s) {
     a.tag_class = f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0;
     const unsigned tiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
     if (tiles == 0) return;
+    if (f.flags & SWR_FLAG_METAL_RULES) {
+        hipLaunchKernelGGL(k_raster_metal, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        return;
+    }
     static const int variant = getenv("SWR_DEBUG_VARIANT") ? atoi(getenv("SWR_DEBUG_VARIANT")) : 0;
     if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 1)
         hipLaunchKernelGGL((k_raster<true, 1>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);

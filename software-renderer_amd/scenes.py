@@ -28,6 +28,7 @@ _M2 = np.uint64(0x94D049BB133111EB)
 
 FLAG_DEPTH_TEST = 1
 FLAG_NO_COLOR = 2
+FLAG_METAL_RULES = 4
 
 
 def splitmix64(seed: int, n: int, offset: int = 0) -> np.ndarray:

@@ -403,3 +403,61 @@ def test_headless_frame_loop_and_obj_loader(oracle, swr, tmp_path):
     assert i.tolist() == [0, 1, 2, 0, 2, 3] and v.shape == (4, 8)
     rc_c, rc_d, _, _ = oracle.render(v, i, frames[0][2], 64, 64, 0)
     assert_same(frames[0][0], frames[0][1], rc_c, rc_d, "obj quad")
+
+
+# ---- the Metal path's rules: SWR_FLAG_METAL_RULES -------------------------
+MR = 4
+
+
+def check_metal(ctx, oracle, scene, extra=0, what=None):
+    rc_c, rc_d, st, rc = oracle.render_metal(scene.vertices, scene.indices, scene.transform,
+                                             scene.width, scene.height, extra)
+    assert rc == 0
+    c, d = ctx.render(scene.vertices, scene.indices, scene.transform, scene.width, scene.height, MR | extra)
+    assert_same(c, d, rc_c, rc_d, what or f"metal {scene.name}")
+    return st
+
+
+def test_metal_rules_cfg1(gpu_ctx, oracle, swr):
+    for g in (False, True):
+        st = check_metal(gpu_ctx, oracle, swr.scenes.cfg1_triangle(g))
+        assert st.fragments_written == 8192
+
+
+@pytest.mark.parametrize("ntri,w,h,r,seed", [
+    (1, 64, 64, 0.5, 1), (300, 256, 256, 0.15, 3), (2000, 640, 360, 0.05, 4), (400, 255, 129, 0.3, 6),
+    (20000, 512, 512, 0.01, 8), (40, 1280, 720, 1.2, 9),
+])
+def test_metal_rules_random_soup(gpu_ctx, oracle, swr, ntri, w, h, r, seed):
+    s = swr.scenes.random_soup(ntri, w, h, 900 + seed, r_ndc=r, margin=1.1, shared=(seed % 2 == 1))
+    st = check_metal(gpu_ctx, oracle, s)
+    assert st.triangles_drawn > 0
+    check_metal(gpu_ctx, oracle, s, NC)                                # depth-only
+
+
+def test_metal_rules_app_scene_and_ties(gpu_ctx, oracle, swr):
+    s = swr.scenes.cfg2_teapot_scale(480, 270)
+    check_metal(gpu_ctx, oracle, s)
+    xyz = np.array([[0.0, 0.8, 0.5], [0.8, -0.8, 0.5], [-0.8, -0.8, 0.5]] * 2, dtype=np.float32)
+    rgb = np.array([[1, 0, 0]] * 3 + [[0, 0, 1]] * 3, dtype=np.float32)
+    t = swr.scenes.Scene("ties", 160, 160, swr.scenes.pack_vertices(xyz, rgb), np.arange(6, dtype=np.int64),
+                         swr.scenes.identity(), 0)
+    check_metal(gpu_ctx, oracle, t)
+    c, _ = gpu_ctx.render(t.vertices, t.indices, t.transform, 160, 160, MR)
+    assert tuple(c[80, 80]) == (0, 0, 255, 255)                        # equal z: first dispatch keeps the pixel
+
+
+def test_metal_rules_bands(swr, oracle):
+    s = swr.scenes.random_soup(3000, 400, 300, 77, r_ndc=0.1, margin=1.05)
+    ref_c, ref_d, _, _ = oracle.render_metal(s.vertices, s.indices, s.transform, 400, 300)
+    color = np.zeros((300, 400, 4), dtype=np.uint8)
+    depth = np.zeros((300, 400), dtype=np.float32)
+    for k in range(3):
+        r0, r1 = swr.band_rows(300, 3, k)
+        with swr.Context() as ctx:
+            ctx.scene_upload(s.vertices, s.indices)
+            ctx.target_set(400, 300, r0, r1)
+            ctx.draw(s.transform, MR)
+            ctx.read_color(color)
+            ctx.read_depth(depth)
+    assert_same(color, depth, ref_c, ref_d, "metal bands")

@@ -242,3 +242,33 @@ def test_line_primitive_only_clears(oracle, swr):
     assert rc == 0 and (c == 0).all() and np.isposinf(d).all()
     assert oracle.render(s.vertices, s.indices[:21], s.transform, 32, 32, 0, primitive_type=1)[3] == -2
     assert oracle.render(s.vertices, s.indices, s.transform, 32, 32, 0, primitive_type=9)[3] == -5
+
+
+# ---- the Metal path's rules ---------------------------------------
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_metal_rules_c_equals_numpy(oracle, swr, seed):
+    s = swr.scenes.random_soup(120, 120, 90, 500 + seed, r_ndc=0.25, margin=1.1, shared=(seed == 2))
+    c, d, st, rc = oracle.render_metal(s.vertices, s.indices, s.transform, 120, 90)
+    c2, d2 = onp.render_metal(s.vertices, s.indices, s.transform, 120, 90)
+    assert rc == 0 and st.fragments_written > 100
+    assert np.array_equal(d.view(np.uint32), d2.view(np.uint32)) and np.array_equal(c, c2)
+
+
+def test_metal_rules_known_answers_and_differences(oracle, swr):
+    """cfg1 under the Metal rules: the ROI is 129 x 129 threads, the inside test keeps the closed
+    triangle (both slanted edges and the bottom edge included, unlike the CPU span rule), the
+    z-test is on and the depth image is written, colours round to nearest."""
+    s = swr.scenes.cfg1_triangle()
+    c, d, st, rc = oracle.render_metal(s.vertices, s.indices, s.transform, 256, 256)
+    cov = c[..., 3] == 255
+    assert rc == 0 and st.fragments == 129 * 129
+    assert cov.sum() == st.fragments_written == 8192
+    assert (c[cov] == (64, 128, 255, 255)).all()              # 63.75 -> 64, 127.5 -> 128 (nearest even)
+    assert np.array_equal(np.isfinite(d), cov) and (d[cov] == np.float32(0.5)).all()
+    cpu, _, _, _ = oracle.render_scene(s)
+    assert ((cpu[..., 3] == 255) != cov).sum() > 100           # the two renderers do NOT agree (SURVEY §0.3)
+    # ROI min-x == 0 -> the host skips the primitive (GpuRenderer.swift:122-124)
+    v = s.vertices.copy()
+    v[2, 0] = -1.0                                              # snaps to x = 0
+    c2, d2, st2, _ = oracle.render_metal(v, s.indices, s.transform, 256, 256)
+    assert st2.triangles_skipped == 1 and (c2 == 0).all() and np.isposinf(d2).all()

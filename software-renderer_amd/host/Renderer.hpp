@@ -161,8 +161,12 @@ private:
 class GpuRenderer {
 public:
     bool depthTest = true;
+    // true: the Metal kernels' own rules (round() snap, ROI threads + inside test, UNORM rounding,
+    // ROI-min == 0 skip; Shaders.metal:57-167, GpuRenderer.swift:122-124) instead of the CPU renderer's
+    bool metalRules = false;
     void render(const RenderPass& renderPass) {
-        ctx_.render(renderPass, depthTest ? (uint32_t)SWR_FLAG_DEPTH_TEST : 0u);
+        ctx_.render(renderPass, metalRules ? (uint32_t)SWR_FLAG_METAL_RULES
+                                           : (depthTest ? (uint32_t)SWR_FLAG_DEPTH_TEST : 0u));
     }
 private:
     detail::Context ctx_;

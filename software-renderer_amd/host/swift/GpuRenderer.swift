@@ -12,6 +12,8 @@ final class GpuRenderer {
     private var ctx: OpaquePointer?
     /// The Metal path z-tests (Shaders.metal:158-165); false reproduces Renderer.swift as written.
     var depthTest = true
+    /// true: the Metal kernels' own rules (SWR_FLAG_METAL_RULES) instead of the CPU renderer's pixel rules.
+    var metalRules = false
 
     init() {
         var cfg = swr_config(device: -1, reserved: 0)
@@ -30,7 +32,7 @@ final class GpuRenderer {
         pass.color_bytes_per_row = Int64(renderPass.colorBuffer.bytesPerRow)
         pass.depth_bytes_per_row = Int64(renderPass.depthBuffer.bytesPerRow)
         pass.primitive_type = renderPass.primitiveType == .triangle ? 0 : (renderPass.primitiveType == .line ? 1 : 2)
-        pass.flags = depthTest ? UInt32(SWR_FLAG_DEPTH_TEST) : 0
+        pass.flags = metalRules ? UInt32(SWR_FLAG_METAL_RULES) : (depthTest ? UInt32(SWR_FLAG_DEPTH_TEST) : 0)
         withUnsafeBytes(of: renderPass.transform) { src in          // matrix_float4x4 = 4 float4 columns
             withUnsafeMutableBytes(of: &pass.transform) { $0.copyMemory(from: src) }
         }

@@ -56,6 +56,20 @@ int main() {
         CHECK(pass.colorBuffer.at(128, 128).a == 255);
         CHECK(pass.colorBuffer.at(128, 40).a == 0);
 
+        // the Metal kernels' own rules: closed triangle, nearest-even UNORM (63.75 -> 64, 127.5 -> 128)
+        pass.vertices = {Vertex(0.0f, 0.5f, 0.5f, 1.0f, 0.5f, 0.25f), Vertex(0.5f, -0.5f, 0.5f, 1.0f, 0.5f, 0.25f),
+                         Vertex(-0.5f, -0.5f, 0.5f, 1.0f, 0.5f, 0.25f)};
+        pass.indices = {0, 1, 2};
+        pass.transform = matrix_float4x4::identity();
+        gpuRenderer.metalRules = true;
+        gpuRenderer.render(pass);
+        gpuRenderer.metalRules = false;
+        long mcov = 0;
+        for (long i = 0; i < W * H; i++) mcov += color[i].a == 255;
+        CHECK(mcov == 8192);
+        CHECK(pass.colorBuffer.at(128, 128).b == 64 && pass.colorBuffer.at(128, 128).g == 128);
+        CHECK(pass.depthBuffer.at(128, 128) == 0.5f);
+
         // the reference traps on a bad index (Renderer.swift:226); the mirror throws
         pass.indices = {0, 1, 99};
         bool threw = false;
@@ -76,7 +90,7 @@ int main() {
         long pts = 0;
         for (long i = 0; i < W * H; i++) pts += color[i].a == 255;
         CHECK(pts == 3);
-        CHECK(pass.colorBuffer.at(128, 25).r == 255);   // vertex (0, .8) -> (128, 25.6 -> 25)
+        CHECK(pass.colorBuffer.at(128, 64).r == 255);   // vertex (0, .5) -> (128, 64)
     } catch (const RenderError& e) {
         std::printf("RenderError %d: %s\n", e.code, e.what());
         return 2;

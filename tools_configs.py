@@ -9,6 +9,9 @@ for name, scene, flags in (("cfg2 torus 6320 tris 1080p painter", S.cfg2_teapot_
                            ("cfg3 torus 69451 tris 4K z-test", S.cfg3_bunny_scale(), 1),
                            ("cfg5 grid 262144 tris 8K z-test", S.cfg5_sponza_scale(), 1),
                            ("big: 300 screen-filling tris 1080p z", S.random_soup(300, 1920, 1080, 91, r_ndc=1.5, flags=1, margin=0.5), 1),
+                           ("cfg4 soup 1M tris 4K METAL rules (colour+depth)", S.cfg4_soup(depth_only=False), 4),
+                           ("cfg4 soup 1M tris 4K CPU rules colour+depth", S.cfg4_soup(depth_only=False), 1),
+                           ("app sphere 338 tris 512^2 METAL rules", None, 4),
                            ("app sphere 338 tris 512^2 z", None, 1)):
     if scene is None:
         import importlib.util

@@ -179,13 +179,26 @@ def main():
         "avg_launch_ms": round(raster_ms, 5), "launches_timed": frames,
         "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 5),
     }
-    # per-stage breakdown from a short separate run with events around every stage (those events
-    # cost stream time, so they stay out of the timed region above)
-    _, sums_all, frames_all = timed(flags, max(args.steps // 10, 5), 2, level=2)
+    # per-stage breakdown from a short separate run with frame pipelining off (stages serialised on
+    # one stream) and events around every stage — those events cost stream time, and under
+    # pipelining the stages of two frames overlap, so this stays out of the timed region above
+    ctx.pipeline_enable(False)
+    dt_iso, sums_all, frames_all = timed(flags, max(args.steps // 4, 5), 2, level=2)
     kernels = {k: round(v / max(frames_all, 1), 5) for k, v in sums_all.items() if k.endswith("_ms")}
+    iso_steps = max(args.steps // 4, 5)
+    _, sums_iso, frames_iso = timed(flags, iso_steps, 2, level=1)
+    ctx.pipeline_enable(True)
     t_last = ctx.timings()
+    raster_iso_ms = sums_iso["raster_ms"] / max(frames_iso, 1)
+    roofline["isolated"] = {
+        "note": "same kernel with frame pipelining off (nothing else on the GPU)",
+        "avg_launch_ms": round(raster_iso_ms, 5),
+        "achieved": round(band_px * bytes_per_px / (raster_iso_ms * 1e-3) / 1e9, 2) if raster_iso_ms > 0 else None,
+        "frac": round(band_px * bytes_per_px / (raster_iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if raster_iso_ms > 0 else None,
+    }
 
     extra = {"frames_per_s": round(args.steps / dt, 2), "kernel_ms_avg": kernels,
+             "kernel_ms_avg_note": "stages serialised (pipelining off); the timed region overlaps binning of frame N+1 with the raster of frame N",
              "tile_pairs": t_last["tile_pairs"], "tiles": t_last["tiles"], "band_rows": [r0, r1],
              "tile": list(swr_amd.tile_shape()),
              "compulsory_bytes_per_frame": band_px * bytes_per_px + 32 * scene.vertices.shape[0] + 8 * scene.indices.size}

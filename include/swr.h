@@ -163,6 +163,11 @@ int swr_get_timings(swr_context* ctx, swr_timings* out);          /* the last fr
 int swr_timing_totals(swr_context* ctx, swr_timings* sum_out, int64_t* frames_out);
 int swr_timing_reset(swr_context* ctx);
 
+/* Frame pipelining (on by default): the binning kernels of the next swr_draw run on a second stream,
+ * over a double-buffered working set, while the previous frame is still being rasterised.  Results
+ * are identical either way; 0 serialises the two stages on one stream (clean per-stage timings). */
+int swr_pipeline_enable(swr_context* ctx, int enable);
+
 /* Tile geometry the band boundaries must respect. */
 int swr_tile_rows(void);
 int swr_tile_cols(void);

@@ -18,7 +18,7 @@ FLAG_METAL_RULES = 4
 ABI_SYMBOLS = [
     "swr_abi_version", "swr_version", "swr_context_create", "swr_context_destroy", "swr_last_error",
     "swr_render", "swr_scene_upload", "swr_target_set", "swr_draw", "swr_draw_primitives", "swr_sync", "swr_read_color",
-    "swr_read_depth", "swr_timing_enable", "swr_get_timings", "swr_timing_totals", "swr_timing_reset", "swr_tile_rows", "swr_tile_cols",
+    "swr_read_depth", "swr_timing_enable", "swr_get_timings", "swr_timing_totals", "swr_timing_reset", "swr_pipeline_enable", "swr_tile_rows", "swr_tile_cols",
     "swr_band_rows",
 ]
 
@@ -102,6 +102,8 @@ def load_library():
     L.swr_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
     L.swr_timing_totals.argtypes = [vp, ctypes.POINTER(Timings), ctypes.POINTER(i64)]
     L.swr_timing_reset.argtypes = [vp]
+    L.swr_pipeline_enable.argtypes = [vp, ctypes.c_int]
+    L.swr_pipeline_enable.restype = ctypes.c_int
     L.swr_band_rows.argtypes = [i64, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
     for name in ("swr_context_create", "swr_render", "swr_scene_upload", "swr_target_set", "swr_draw",
                  "swr_sync", "swr_read_color", "swr_read_depth", "swr_timing_enable", "swr_get_timings", "swr_timing_totals", "swr_timing_reset",
@@ -207,6 +209,10 @@ class Context:
         t, n = Timings(), ctypes.c_int64()
         self._check(self._L.swr_timing_totals(self._h, ctypes.byref(t), ctypes.byref(n)))
         return t.as_dict(), n.value
+
+    def pipeline_enable(self, on: bool = True):
+        """Overlap binning of the next frame with the raster of the previous one (default on)."""
+        self._check(self._L.swr_pipeline_enable(self._h, 1 if on else 0))
 
     def timing_reset(self):
         self._check(self._L.swr_timing_reset(self._h))

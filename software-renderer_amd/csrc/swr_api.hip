@@ -32,7 +32,7 @@ struct swr_context {
     std::string err;
 
     // scene (RenderPass.vertices / .indices)
-    DevBuf vertices, indices, xyz, rgb, idx32, geo, geo_full;
+    DevBuf vertices, indices, xyz, rgb, idx32;
     int64_t nv = 0, ni = 0;
     bool has_scene = false;
 
@@ -40,8 +40,18 @@ struct swr_context {
     Target tg{};
     bool has_target = false;
     DevBuf color, depth;
-    DevBuf tilebuf;            // [CNT_WORDS counters][tiles tile_count][tiles+1 tile_start][tiles cursor]
-    DevBuf ranges, bins, bin_matrix;
+    // Per-frame working set, double-buffered: the binning kernels of frame N+1 run on `bin_stream`
+    // while k_raster of frame N runs on `stream` (HBM-bound vs LDS/VALU-bound: they overlap well).
+    struct Slot {
+        DevBuf geo, geo_full, ranges, bins, bin_matrix;
+        DevBuf tilebuf;        // [CNT_WORDS counters][tiles tile_count][tiles+1 tile_start][tiles cursor]
+        hipEvent_t bin_done = nullptr, ras_done = nullptr;
+        bool ras_recorded = false;
+    } slot[2];
+    hipStream_t bin_stream = nullptr;   // the stream binning is enqueued on (== stream when pipelining is off)
+    hipStream_t bin_stream_own = nullptr;
+    uint64_t frame_no = 0;
+    int last_slot = 0;
     uint32_t capacity = 0;
 
     uint32_t* h_counters = nullptr;   // pinned, mapped into the device address space
@@ -104,14 +114,22 @@ int ensure(swr_context* c, DevBuf& b, size_t bytes) {
 int ensure_capacity(swr_context* c, uint32_t cap) {
     if (cap <= c->capacity) return SWR_OK;
     int rc;
-    if ((rc = ensure(c, c->bins, (size_t)cap * 4))) return rc;
+    for (auto& sl : c->slot)
+        if ((rc = ensure(c, sl.bins, (size_t)cap * 4))) return rc;
     c->capacity = cap;
+    return SWR_OK;
+}
+
+int sync_streams(swr_context* c) {
+    HIP_TRY(c, hipStreamSynchronize(c->bin_stream));
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SWR_OK;
 }
 
 inline int tiles_of(const Target& t) { return t.tiles_x * t.tiles_y; }
 
-DeviceFrame make_frame(swr_context* c, const float m[16], uint32_t flags) {
+DeviceFrame make_frame(swr_context* c, int si, const float m[16], uint32_t flags) {
+    swr_context::Slot& sl = c->slot[si];
     DeviceFrame f{};
     f.vertices = (const swr_vertex*)c->vertices.p;
     f.indices = (const int64_t*)c->indices.p;
@@ -120,18 +138,18 @@ DeviceFrame make_frame(swr_context* c, const float m[16], uint32_t flags) {
     f.idx32 = (const uint32_t*)c->idx32.p;
     f.vertex_count = c->nv;
     f.ntri = c->ni / 3;
-    f.geo = (GeomRec*)c->geo.p;
-    f.geo_full = (GeomFull*)c->geo_full.p;
-    uint32_t* tb = (uint32_t*)c->tilebuf.p;
+    f.geo = (GeomRec*)sl.geo.p;
+    f.geo_full = (GeomFull*)sl.geo_full.p;
+    uint32_t* tb = (uint32_t*)sl.tilebuf.p;
     f.counters = tb;
     f.host_counters = c->h_counters_dev;
     f.tile_count = tb + CNT_WORDS;
     f.tile_start = tb + CNT_WORDS + tiles_of(c->tg);
     f.tile_cursor = tb + CNT_WORDS + 2 * tiles_of(c->tg) + 1;
-    f.ranges = (uint2*)c->ranges.p;
+    f.ranges = (uint2*)sl.ranges.p;
     f.plan = plan_binning(f.ntri, tiles_of(c->tg));
-    f.bin_matrix = (uint32_t*)c->bin_matrix.p;
-    f.bins = (uint32_t*)c->bins.p;
+    f.bin_matrix = (uint32_t*)sl.bin_matrix.p;
+    f.bins = (uint32_t*)sl.bins.p;
     f.capacity = c->capacity;
     f.color = (uint8_t*)c->color.p;
     f.depth = (float*)c->depth.p;
@@ -164,48 +182,67 @@ int enqueue_frame(swr_context* c) {
     {
         const BinPlan plan = plan_binning(c->ni / 3, tiles_of(c->tg));
         if (plan.use_lds) {
-            int rc = ensure(c, c->bin_matrix, (size_t)plan.G * (size_t)tiles_of(c->tg) * 4);
-            if (rc) return rc;
+            const size_t need = (size_t)plan.G * (size_t)tiles_of(c->tg) * 4;
+            if (c->slot[0].bin_matrix.bytes < need || c->slot[1].bin_matrix.bytes < need) {
+                int rc = sync_streams(c);
+                if (rc) return rc;
+                for (auto& sl : c->slot)
+                    if ((rc = ensure(c, sl.bin_matrix, need))) return rc;
+            }
         }
     }
-    DeviceFrame f = make_frame(c, c->last_m, c->last_flags);
     if (c->last_prim != SWR_PRIMITIVE_TRIANGLE) {
         // .vertices / .line: three small kernels, no binning; the pair counter reads 0
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        int rc = sync_streams(c);
+        if (rc) return rc;
+        DeviceFrame f = make_frame(c, 0, c->last_m, c->last_flags);
         c->h_counters[CNT_PAIRS] = 0;
         launch_points_or_lines(f, c->last_prim, c->stream);
         HIP_TRY(c, hipGetLastError());
         c->draw_pending = true;
         return SWR_OK;
     }
+    const int si = (int)(c->frame_no++ & 1);
+    c->last_slot = si;
+    swr_context::Slot& sl = c->slot[si];
+    DeviceFrame f = make_frame(c, si, c->last_m, c->last_flags);
     hipEvent_t* ev = nullptr;
     if (c->timing) {
         if (c->seq - c->harvested >= (uint64_t)swr_context::RING) {   // ring full: drain it
-            HIP_TRY(c, hipStreamSynchronize(c->stream));
+            int rc = sync_streams(c);
+            if (rc) return rc;
             harvest(c);
         }
         ev = c->ev[c->seq % swr_context::RING];
         c->ev_level[c->seq % swr_context::RING] = c->timing;
         c->seq++;
     }
+    hipStream_t sb = c->bin_stream, sr = c->stream;
+    // this slot's buffers are free again once the raster of two frames ago has read them
+    if (sl.ras_recorded && sb != sr) HIP_TRY(c, hipStreamWaitEvent(sb, sl.ras_done, 0));
     if (!f.plan.use_lds || f.ntri <= 0) {
         // global-atomic fallback: counters must start at zero.  Empty scene: no binning kernel
         // runs at all, so the tile table (counts, starts, counters) is simply zeroed.
-        if (f.ntri <= 0) { HIP_TRY(c, hipStreamSynchronize(c->stream)); c->h_counters[CNT_PAIRS] = 0; }
+        if (f.ntri <= 0) { int rc = sync_streams(c); if (rc) return rc; c->h_counters[CNT_PAIRS] = 0; }
         const size_t zero_bytes = (size_t)(CNT_WORDS + 3 * tiles_of(c->tg) + 1) * 4;
-        HIP_TRY(c, hipMemsetAsync(c->tilebuf.p, 0, zero_bytes, c->stream));
+        HIP_TRY(c, hipMemsetAsync(sl.tilebuf.p, 0, zero_bytes, sb));
     }
     const bool all = c->timing >= 2;
-    if (ev && all) HIP_TRY(c, hipEventRecord(ev[0], c->stream));
-    launch_setup_bin(f, c->stream);
-    if (ev && all) HIP_TRY(c, hipEventRecord(ev[1], c->stream));
-    launch_scan(f, c->stream);
-    if (ev && all) HIP_TRY(c, hipEventRecord(ev[2], c->stream));
-    launch_fill(f, c->stream);
-    launch_sort_bins(f, c->stream);
-    if (ev) HIP_TRY(c, hipEventRecord(ev[3], c->stream));
-    launch_raster(f, c->stream);
-    if (ev) HIP_TRY(c, hipEventRecord(ev[4], c->stream));
+    if (ev && all) HIP_TRY(c, hipEventRecord(ev[0], sb));
+    launch_setup_bin(f, sb);
+    if (ev && all) HIP_TRY(c, hipEventRecord(ev[1], sb));
+    launch_scan(f, sb);
+    if (ev && all) HIP_TRY(c, hipEventRecord(ev[2], sb));
+    launch_fill(f, sb);
+    launch_sort_bins(f, sb);
+    if (sb != sr) {
+        HIP_TRY(c, hipEventRecord(sl.bin_done, sb));
+        HIP_TRY(c, hipStreamWaitEvent(sr, sl.bin_done, 0));
+    }
+    if (ev) HIP_TRY(c, hipEventRecord(ev[3], sr));
+    launch_raster(f, sr);
+    if (ev) HIP_TRY(c, hipEventRecord(ev[4], sr));
+    if (sb != sr) { HIP_TRY(c, hipEventRecord(sl.ras_done, sr)); sl.ras_recorded = true; }
     HIP_TRY(c, hipGetLastError());
     c->draw_pending = true;   // the pair total lands in h_counters[CNT_PAIRS] (written by the scan)
     return SWR_OK;
@@ -257,6 +294,26 @@ int swr_context_create(const swr_config* cfg, swr_context** out) {
         return rc;
     }
     memset(c->h_counters, 0, CNT_WORDS * 4);
+    {
+        // SWR_PIPELINE=0: binning and raster share one stream (no overlap of consecutive frames)
+        const char* pl = getenv("SWR_PIPELINE");
+        if (pl && pl[0] == '0') c->bin_stream = c->stream;
+        else {
+            // SWR_PIPELINE=2: plain second stream; default: the binning stream gets the lowest priority so
+            // that raster workgroups win the CUs and the HBM-bound binning kernels fill the gaps
+            int least = 0, greatest = 0;
+            hipDeviceGetStreamPriorityRange(&least, &greatest);
+            hipError_t pe = (pl && pl[0] == '2')
+                                ? hipStreamCreateWithFlags(&c->bin_stream, hipStreamNonBlocking)
+                                : hipStreamCreateWithPriority(&c->bin_stream, hipStreamNonBlocking, least);
+            if (pe != hipSuccess) c->bin_stream = c->stream;
+            else c->bin_stream_own = c->bin_stream;
+        }
+        for (auto& sl : c->slot) {
+            hipEventCreateWithFlags(&sl.bin_done, hipEventDisableTiming);
+            hipEventCreateWithFlags(&sl.ras_done, hipEventDisableTiming);
+        }
+    }
     for (int r = 0; r < swr_context::RING; r++)
         for (int i = 0; i < 5; i++) hipEventCreate(&c->ev[r][i]);
     c->ev_ok = true;
@@ -267,10 +324,17 @@ int swr_context_create(const swr_config* cfg, swr_context** out) {
 void swr_context_destroy(swr_context* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    if (c->bin_stream) hipStreamSynchronize(c->bin_stream);
     if (c->stream) hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->xyz, &c->rgb, &c->idx32, &c->geo, &c->geo_full, &c->color, &c->depth, &c->tilebuf,
-                      &c->ranges, &c->bins, &c->bin_matrix};
+    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->xyz, &c->rgb, &c->idx32, &c->color, &c->depth};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
+    for (auto& sl : c->slot) {
+        DevBuf* sb[] = {&sl.geo, &sl.geo_full, &sl.ranges, &sl.bins, &sl.bin_matrix, &sl.tilebuf};
+        for (DevBuf* b : sb) if (b->p) hipFree(b->p);
+        if (sl.bin_done) hipEventDestroy(sl.bin_done);
+        if (sl.ras_done) hipEventDestroy(sl.ras_done);
+    }
+    if (c->bin_stream_own) hipStreamDestroy(c->bin_stream_own);
     if (c->h_counters) hipHostFree(c->h_counters);
     if (c->ev_ok)
         for (int r = 0; r < swr_context::RING; r++)
@@ -287,7 +351,7 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     if (index_count / 3 >= 0xFFFFFFFFll || vertex_count > 0xFFFFFFFFll)
         return fail(c, SWR_ERR_UNSUPPORTED, "more than 2^32-2 primitives or 2^32 vertices");
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rcs = sync_streams(c); if (rcs) return rcs; }
     c->has_scene = false;
     c->draw_pending = false;
     int rc;
@@ -296,22 +360,24 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     if ((rc = ensure(c, c->xyz, (size_t)vertex_count * 16))) return rc;
     if ((rc = ensure(c, c->rgb, (size_t)vertex_count * 16))) return rc;
     if ((rc = ensure(c, c->idx32, (size_t)index_count * 4))) return rc;
-    if ((rc = ensure(c, c->geo, (size_t)(index_count / 3) * sizeof(GeomRec)))) return rc;
-    if ((rc = ensure(c, c->geo_full, (size_t)(index_count / 3) * sizeof(GeomFull)))) return rc;
-    if ((rc = ensure(c, c->ranges, (size_t)(index_count / 3) * sizeof(uint2)))) return rc;
-    if ((rc = ensure(c, c->tilebuf, (size_t)(CNT_WORDS + 3 * std::max(1, tiles_of(c->tg)) + 1) * 4))) return rc;
+    for (auto& sl : c->slot) {
+        if ((rc = ensure(c, sl.geo, (size_t)(index_count / 3) * sizeof(GeomRec)))) return rc;
+        if ((rc = ensure(c, sl.geo_full, (size_t)(index_count / 3) * sizeof(GeomFull)))) return rc;
+        if ((rc = ensure(c, sl.ranges, (size_t)(index_count / 3) * sizeof(uint2)))) return rc;
+        if ((rc = ensure(c, sl.tilebuf, (size_t)(CNT_WORDS + 3 * std::max(1, tiles_of(c->tg)) + 1) * 4))) return rc;
+    }
     if (vertex_count)
         HIP_TRY(c, hipMemcpyAsync(c->vertices.p, vertices, (size_t)vertex_count * sizeof(swr_vertex),
                                   hipMemcpyHostToDevice, c->stream));
     if (index_count)
         HIP_TRY(c, hipMemcpyAsync(c->indices.p, indices, (size_t)index_count * 8, hipMemcpyHostToDevice, c->stream));
     // index range check (Swift array subscript would trap, Renderer.swift:226)
-    HIP_TRY(c, hipMemsetAsync(c->tilebuf.p, 0, CNT_WORDS * 4, c->stream));
-    launch_validate_indices((const int64_t*)c->indices.p, index_count, vertex_count, (uint32_t*)c->tilebuf.p, c->stream);
+    HIP_TRY(c, hipMemsetAsync(c->slot[0].tilebuf.p, 0, CNT_WORDS * 4, c->stream));
+    launch_validate_indices((const int64_t*)c->indices.p, index_count, vertex_count, (uint32_t*)c->slot[0].tilebuf.p, c->stream);
     launch_split_scene((const swr_vertex*)c->vertices.p, vertex_count, (const int64_t*)c->indices.p, index_count,
                        (float4*)c->xyz.p, (float4*)c->rgb.p, (uint32_t*)c->idx32.p, c->stream);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->tilebuf.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->slot[0].tilebuf.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->h_counters[CNT_BAD_INDEX])
         return fail(c, SWR_ERR_INDEX_RANGE, "an index is outside [0, %lld)", (long long)vertex_count);
@@ -330,7 +396,7 @@ int swr_target_set(swr_context* c, int64_t width, int64_t height, int64_t row_be
         return fail(c, SWR_ERR_BAD_ARG, "bad band [%lld,%lld): row_begin must be a multiple of %d",
                     (long long)row_begin, (long long)row_end, TILE_H);
     HIP_TRY(c, hipSetDevice(c->device));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    { int rcs = sync_streams(c); if (rcs) return rcs; }
     c->draw_pending = false;
     Target t;
     t.width = (int32_t)width; t.height = (int32_t)height;
@@ -341,7 +407,8 @@ int swr_target_set(swr_context* c, int64_t width, int64_t height, int64_t row_be
     int rc;
     if ((rc = ensure(c, c->color, px * 4))) return rc;
     if ((rc = ensure(c, c->depth, px * 4))) return rc;
-    if ((rc = ensure(c, c->tilebuf, (size_t)(CNT_WORDS + 3 * std::max(1, tiles_of(t)) + 1) * 4))) return rc;
+    for (auto& sl : c->slot)
+        if ((rc = ensure(c, sl.tilebuf, (size_t)(CNT_WORDS + 3 * std::max(1, tiles_of(t)) + 1) * 4))) return rc;
     c->tg = t;
     c->has_target = true;
     return SWR_OK;
@@ -376,7 +443,7 @@ int swr_sync(swr_context* c) {
     if (!c) return SWR_ERR_BAD_ARG;
     HIP_TRY(c, hipSetDevice(c->device));
     for (int attempt = 0; attempt < 8; attempt++) {
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        { int rcs = sync_streams(c); if (rcs) return rcs; }
         if (!c->draw_pending) { harvest(c); return SWR_OK; }
         const uint32_t pairs = c->h_counters[CNT_PAIRS];
         if (pairs <= c->capacity) {
@@ -424,6 +491,14 @@ int swr_timing_enable(swr_context* c, int enable) {
     int rc = swr_sync(c);
     if (rc) return rc;
     c->timing = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
+    return SWR_OK;
+}
+
+int swr_pipeline_enable(swr_context* c, int enable) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    int rc = swr_sync(c);
+    if (rc) return rc;
+    c->bin_stream = (enable && c->bin_stream_own) ? c->bin_stream_own : c->stream;
     return SWR_OK;
 }
 

@@ -461,3 +461,25 @@ def test_metal_rules_bands(swr, oracle):
             ctx.read_color(color)
             ctx.read_depth(depth)
     assert_same(color, depth, ref_c, ref_d, "metal bands")
+
+
+def test_frames_in_flight_pipelining(gpu_ctx, oracle, swr):
+    """Binning of frame N+1 overlaps the raster of frame N (two streams, double-buffered working
+    set): queue many frames with different transforms / flags without a sync; the image read is
+    that of the last draw, and a read after every draw also matches."""
+    s = swr.scenes.cfg2_teapot_scale(400, 300)
+    gpu_ctx.scene_upload(s.vertices, s.indices)
+    gpu_ctx.target_set(400, 300)
+    ms = [swr.scenes.app_transform(0.3 * k) for k in range(9)]
+    for rounds in (1, 2, 3, 9):
+        for k in range(rounds):
+            gpu_ctx.draw(ms[k], DT if k % 2 == 0 else 0)        # alternate z-test / painter
+        k = rounds - 1
+        c, d = gpu_ctx.read_color(), gpu_ctx.read_depth()
+        rc, rd, _, _ = oracle.render(s.vertices, s.indices, ms[k], 400, 300, (DT if k % 2 == 0 else 0) | oracle.TINV_PER_TRIANGLE)
+        assert_same(c, d, rc, rd, f"pipelined rounds={rounds}")
+    for k in range(4):
+        gpu_ctx.draw(ms[k], DT)
+        c, d = gpu_ctx.read_color(), gpu_ctx.read_depth()
+        rc, rd, _, _ = oracle.render(s.vertices, s.indices, ms[k], 400, 300, DT | oracle.TINV_PER_TRIANGLE)
+        assert_same(c, d, rc, rd, f"draw+read {k}")

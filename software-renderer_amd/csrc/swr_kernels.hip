@@ -1,22 +1,27 @@
 // swr_kernels.hip — gfx950 (CDNA4, wave64) kernels of the triangle hot path.
 //
-// Pipeline of one frame (all on one stream, no host round trip):
-//   k_setup_hist  1 lane / triangle : vertex_shader x3, /w, screen map, truncation, y-sort,
-//                                     validity via T(), 32-B GeomRec; bbox -> tile
-//                                     rectangle (8 B/triangle); per-workgroup tile histogram in LDS
-//   k_colscan     16 tiles / block  : prefix of the (workgroup x tile) count matrix over workgroups
-//   k_scan        1 workgroup       : exclusive scan of the per-tile totals
-//   k_fill_lds    1 lane / triangle : bins[ds_add_rtn(cursor[tile])] = prim, cursors seeded from
-//                                     tile_start + matrix row  (no global atomics anywhere;
-//                                     k_setup_bin / k_fill = global-atomic fallback for tile tables
-//                                     that do not fit LDS)
-//   k_raster      1 workgroup / tile: 64-bit visibility keys for the tile live in LDS; every
-//                                     lane walks the scanline spans of ITS OWN triangle and
-//                                     ds_min_u64's (depth|prim) keys into the tile; big triangles
-//                                     are walked by the whole wave (lane = pixel of a row chunk);
-//                                     resolve: key -> winning primitive -> barycentric colour ->
-//                                     fragment_shader -> one coalesced 16-B/lane framebuffer write
-//                                     (clear fused: HBM sees each pixel exactly once).
+// One frame (no host round trip; binning runs on its own stream, one frame ahead of the raster):
+//   k_setup_hist  1 lane / triangle : vertex_shader x3, /w, screen map, truncation (or round() under
+//                                     the Metal rules), y-sort, validity via T(); 32-B GeomRec;
+//                                     band-clipped pixel bbox (8 B/triangle); per-workgroup tile
+//                                     histogram in LDS -> row of the (workgroup x tile) matrix
+//   k_colscan     16 tiles / block  : exclusive prefix of every matrix column over workgroups
+//   k_fill_lds    1 lane / triangle : every workgroup scans the tile totals in LDS, seeds its cursors
+//                                     with tile_start + matrix row, bins[ds_add_rtn(cursor)] = prim|class
+//                                     (no global atomics anywhere; k_setup_bin / k_scan / k_fill are the
+//                                     global-atomic fallback for tile tables that do not fit LDS)
+//   k_sort_bins   1 workgroup / tile: counting sort of the bin by size class (rows inside the tile)
+//   k_raster      1 workgroup / tile: 64-bit visibility keys of the tile live in LDS.  lane = triangle
+//                                     walks the rows of its own triangle; the spans of a row step are
+//                                     cut into 4-pixel units, prefix-summed across the wave and dealt
+//                                     out densely, lane = unit: owner found by a marker scatter + DPP
+//                                     max-scan, its constants from an LDS table, 4 x (weights, depth,
+//                                     ds_min_u64).  Resolve: key -> winning primitive -> barycentric
+//                                     colour -> fragment_shader -> one 16-B/lane framebuffer store per
+//                                     4 pixels (clear fused: HBM sees each pixel exactly once).
+//   k_raster_metal                  : the same frame under the Metal path's rules (SWR_FLAG_METAL_RULES)
+//   k_points / k_points_resolve     : PrimitiveType .vertices;  k_clear_band: .line (reference stub)
+//   k_split_scene, k_validate_indices: once per swr_scene_upload
 //
 // Semantics restated from renderer/Renderer.swift (reference file:line cited inline):
 //   visibility without z-test = highest primitive index covering the pixel (painter's order of

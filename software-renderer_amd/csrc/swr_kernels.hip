@@ -721,6 +721,7 @@ template <bool ZTEST, int VAR = 0>
 __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
     constexpr int SUPER = 2;   // dense steps whose owner search is done together
     constexpr int UNIT = 4;    // consecutive pixels of one span handled by one lane of a dense step
+    __shared__ uint32_t next_chunk;           // work-stealing cursor over the chunks of the sorted bin
     __shared__ float4 tabA[RASTER_THREADS];   // per triangle of the batch: t00, t01, t10, t11
     __shared__ float4 tabB[RASTER_THREADS];   //                            za, zb, zc, cf.y
     __shared__ uint32_t span_mark[RASTER_THREADS / 64][64 * SUPER];
@@ -745,14 +746,19 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
     uint32_t prim_pre = 0u;
     int4 q0_pre = make_int4(0, 0, 0, 0);
     float4 q1_pre = make_float4(0, 0, 0, 0);
-    // A batch of cnt <= 256 sorted entries goes to the waves in contiguous chunks: 64 per wave when
-    // the grid saturates the chip (fewest row steps in total), cnt/4 per wave when it does not
-    // (small scenes: shortest critical path).  Either way a wave sees a narrow range of sizes.
+    // The sorted bin is cut into contiguous chunks of `csz` entries (one per lane): 64 when the grid
+    // saturates the chip (fewest row steps in total), m/4 when it does not (small scenes: shortest
+    // critical path).  The first 4 chunks go to the 4 waves statically (their gathers are issued
+    // right here); after that a wave that finishes its chunk steals the next one from an LDS counter.
+    // Chunks are heaviest-first, so the stolen ones are the light ones: the waves of a tile finish
+    // together instead of waiting at the final barrier for the wave that drew the heavy chunks.
     const bool spread = gridDim.x <= 1536;   // fewer tiles than the chip holds workgroups (256 CUs x 6)
-    const uint32_t cnt0 = min(m, (uint32_t)RASTER_THREADS);
-    const uint32_t per0 = spread ? (cnt0 + RASTER_THREADS / 64 - 1) / (RASTER_THREADS / 64) : 64u;
-    const uint32_t slot0 = (uint32_t)(tid >> 6) * per0 + (uint32_t)lane;
-    const bool have0 = (uint32_t)lane < per0 && slot0 < cnt0;
+    const uint32_t csz = spread ? min(64u, max(1u, (m + RASTER_THREADS / 64 - 1) / (RASTER_THREADS / 64))) : 64u;
+    const uint32_t nchunks = (m + csz - 1) / csz;
+    uint32_t chunk = (uint32_t)(tid >> 6);
+    if (tid == 0) next_chunk = RASTER_THREADS / 64;
+    const uint32_t slot0 = chunk * csz + (uint32_t)lane;
+    const bool have0 = (uint32_t)lane < csz && slot0 < m;
     if (have0 && VAR != 9 && VAR != 11) {
         prim_pre = a.bins[b0 + slot0];
         q0_pre = reinterpret_cast<const int4*>(a.geo + prim_pre)[0];
@@ -765,12 +771,10 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
     int tag = 0;               // marker generation of this wave (25 bits: never wraps in one launch)
     __syncthreads();
 
-    for (uint32_t base0 = 0; VAR != 9 && VAR != 11 && base0 < m; base0 += RASTER_THREADS) {
-        const uint32_t cnt = min(m - base0, (uint32_t)RASTER_THREADS);
-        const uint32_t per = spread ? (cnt + RASTER_THREADS / 64 - 1) / (RASTER_THREADS / 64) : 64u;
-        const uint32_t slot = (uint32_t)(tid >> 6) * per + (uint32_t)lane;
-        const bool have = (uint32_t)lane < per && slot < cnt;
-        const uint32_t e = base0 + slot;
+    bool first_chunk = true;
+    while (VAR != 9 && VAR != 11 && chunk < nchunks) {
+        const uint32_t e = chunk * csz + (uint32_t)lane;
+        const bool have = (uint32_t)lane < csz && e < m;
         TriState t;
         int ya = 1, yb = 0, bxa = 0, bxb = -1;
         bool big = false;
@@ -779,7 +783,7 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
             uint32_t prim = prim_pre;
             int4 q0 = q0_pre;
             float4 q1 = q1_pre;
-            if (base0 != 0) {
+            if (!first_chunk) {
                 prim = a.bins[b0 + e];
                 q0 = reinterpret_cast<const int4*>(a.geo + prim)[0];
                 q1 = reinterpret_cast<const float4*>(a.geo + prim)[1];
@@ -948,6 +952,11 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
                 }
             }
         }
+        // steal the next chunk (wave-uniform)
+        first_chunk = false;
+        uint32_t nx = 0u;
+        if (lane == 0) nx = atomicAdd(&next_chunk, 1u);
+        chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
     }
     __syncthreads();
 

@@ -161,7 +161,7 @@ def main():
         return dt, sums, frames
 
     flags = scene.flags
-    dt, sums, frames = timed(flags, args.steps, args.warmup)
+    dt, sums, frames = timed(flags, args.steps, args.warmup, level=int(os.environ.get("SWR_BENCH_TIMING_LEVEL", "1")))
     ms_per_step = dt / args.steps * 1e3
     mpix = W * H * args.steps / dt / 1e6
 

@@ -40,14 +40,15 @@ struct swr_context {
     Target tg{};
     bool has_target = false;
     DevBuf color, depth;
-    // Per-frame working set, double-buffered: the binning kernels of frame N+1 run on `bin_stream`
+    static constexpr int NSLOT = 2;
+    // Per-frame working set, multi-buffered: the binning kernels of frame N+1 run on `bin_stream`
     // while k_raster of frame N runs on `stream` (HBM-bound vs LDS/VALU-bound: they overlap well).
     struct Slot {
         DevBuf geo, geo_full, ranges, bins, bin_matrix;
         DevBuf tilebuf;        // [CNT_WORDS counters][tiles tile_count][tiles+1 tile_start][tiles cursor]
         hipEvent_t bin_done = nullptr, ras_done = nullptr;
         bool ras_recorded = false;
-    } slot[2];
+    } slot[NSLOT];
     hipStream_t bin_stream = nullptr;   // the stream binning is enqueued on (== stream when pipelining is off)
     hipStream_t bin_stream_own = nullptr;
     uint64_t frame_no = 0;
@@ -183,7 +184,9 @@ int enqueue_frame(swr_context* c) {
         const BinPlan plan = plan_binning(c->ni / 3, tiles_of(c->tg));
         if (plan.use_lds) {
             const size_t need = (size_t)plan.G * (size_t)tiles_of(c->tg) * 4;
-            if (c->slot[0].bin_matrix.bytes < need || c->slot[1].bin_matrix.bytes < need) {
+            bool grow = false;
+            for (auto& sl : c->slot) grow = grow || sl.bin_matrix.bytes < need;
+            if (grow) {
                 int rc = sync_streams(c);
                 if (rc) return rc;
                 for (auto& sl : c->slot)
@@ -202,7 +205,7 @@ int enqueue_frame(swr_context* c) {
         c->draw_pending = true;
         return SWR_OK;
     }
-    const int si = (int)(c->frame_no++ & 1);
+    const int si = (int)(c->frame_no++ % swr_context::NSLOT);
     c->last_slot = si;
     swr_context::Slot& sl = c->slot[si];
     DeviceFrame f = make_frame(c, si, c->last_m, c->last_flags);
@@ -299,14 +302,9 @@ int swr_context_create(const swr_config* cfg, swr_context** out) {
         const char* pl = getenv("SWR_PIPELINE");
         if (pl && pl[0] == '0') c->bin_stream = c->stream;
         else {
-            // SWR_PIPELINE=2: plain second stream; default: the binning stream gets the lowest priority so
-            // that raster workgroups win the CUs and the HBM-bound binning kernels fill the gaps
-            int least = 0, greatest = 0;
-            hipDeviceGetStreamPriorityRange(&least, &greatest);
-            hipError_t pe = (pl && pl[0] == '2')
-                                ? hipStreamCreateWithFlags(&c->bin_stream, hipStreamNonBlocking)
-                                : hipStreamCreateWithPriority(&c->bin_stream, hipStreamNonBlocking, least);
-            if (pe != hipSuccess) c->bin_stream = c->stream;
+            // a plain second stream: stream priorities (binning highest or lowest) were measured to make
+            // no difference to how the two queues share the CUs on this platform
+            if (hipStreamCreateWithFlags(&c->bin_stream, hipStreamNonBlocking) != hipSuccess) c->bin_stream = c->stream;
             else c->bin_stream_own = c->bin_stream;
         }
         for (auto& sl : c->slot) {

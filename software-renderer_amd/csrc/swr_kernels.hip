@@ -356,13 +356,15 @@ __device__ __forceinline__ void for_each_tile(const PixBox& b, uint32_t p, F&& f
     }
 }
 
+constexpr int BIN_THREADS = 1024;  // workgroup size of k_setup_hist / k_fill_lds (512 measured no better beside raster workgroups)
+
 // ---- binning, LDS path (default): no global atomics ------------------------------------------
 // Workgroup g owns the contiguous chunk [g*chunk, (g+1)*chunk) of the primitives in BOTH walks.
 // k_setup_hist: per-workgroup tile histogram in LDS (ds_add), written as row g of the matrix
 // M[G][tiles].  k_colscan turns every column into an exclusive prefix over g and emits the
 // per-tile totals; k_scan scans the totals; k_fill_lds seeds its LDS cursors with
 // tile_start[t] + M[g][t] and hands out bin positions with returning LDS atomics.
-__global__ __launch_bounds__(1024) void k_setup_hist(SetupArgs a, uint32_t* __restrict__ M,
+__global__ __launch_bounds__(BIN_THREADS) void k_setup_hist(SetupArgs a, uint32_t* __restrict__ M,
                                                      int chunk, int ntiles) {
     extern __shared__ uint32_t hist[];
     for (int e = threadIdx.x; e < ntiles; e += blockDim.x) hist[e] = 0u;
@@ -416,7 +418,7 @@ __global__ __launch_bounds__(256) void k_colscan(uint32_t* __restrict__ M, int G
     if (seg == 15 && e < ntiles) tile_count[e] = run;
 }
 
-__global__ __launch_bounds__(1024) void k_fill_lds(const uint2* __restrict__ ranges, int64_t ntri,
+__global__ __launch_bounds__(BIN_THREADS) void k_fill_lds(const uint2* __restrict__ ranges, int64_t ntri,
                                                    const uint32_t* __restrict__ M,
                                                    const uint32_t* __restrict__ tile_count,
                                                    uint32_t* __restrict__ tile_start,
@@ -426,30 +428,30 @@ __global__ __launch_bounds__(1024) void k_fill_lds(const uint2* __restrict__ ran
                                                    int chunk, int ntiles, int tiles_x, int tag_class) {
     extern __shared__ uint32_t lds[];
     uint32_t* cursor = lds;             // [ntiles]
-    uint32_t* part = lds + ntiles;      // [1024]
+    uint32_t* part = lds + ntiles;      // [BIN_THREADS]
     const int t = threadIdx.x;
     // Every workgroup scans the per-tile totals itself (16 KB from L2, ~1 us) instead of waiting
     // for a single-workgroup scan kernel; workgroup 0 publishes tile_start and the pair total.
-    for (int e = t; e < ntiles; e += 1024) cursor[e] = tile_count[e];
+    for (int e = t; e < ntiles; e += BIN_THREADS) cursor[e] = tile_count[e];
     __syncthreads();
-    const int per = (ntiles + 1023) / 1024;
+    const int per = (ntiles + BIN_THREADS - 1) / BIN_THREADS;
     const int sb = t * per, se = min(sb + per, ntiles);
     uint32_t sum = 0;
     for (int i = sb; i < se; i++) sum += cursor[i];
     part[t] = sum;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) {
+    for (int off = 1; off < BIN_THREADS; off <<= 1) {
         const uint32_t v = (t >= off) ? part[t - off] : 0u;
         __syncthreads();
         part[t] += v;
         __syncthreads();
     }
-    const uint32_t total = part[1023];
+    const uint32_t total = part[BIN_THREADS - 1];
     uint32_t run = part[t] - sum;
     for (int i = sb; i < se; i++) { const uint32_t c = cursor[i]; cursor[i] = run; run += c; }
     __syncthreads();
     if (blockIdx.x == 0) {
-        for (int e = t; e < ntiles; e += 1024) tile_start[e] = cursor[e];
+        for (int e = t; e < ntiles; e += BIN_THREADS) tile_start[e] = cursor[e];
         if (t == 0) {
             tile_start[ntiles] = total;
             counters[CNT_PAIRS] = total;                  // read by k_sort_bins / k_raster
@@ -459,11 +461,11 @@ __global__ __launch_bounds__(1024) void k_fill_lds(const uint2* __restrict__ ran
     }
     if (total > capacity) return;   // overflow: the host grows the bins and redraws
     const uint32_t* row = M + (size_t)blockIdx.x * (size_t)ntiles;
-    for (int e = t; e < ntiles; e += 1024) cursor[e] += row[e];
+    for (int e = t; e < ntiles; e += BIN_THREADS) cursor[e] += row[e];
     __syncthreads();
     const int64_t p0 = (int64_t)blockIdx.x * chunk;
     const int64_t p1 = min(p0 + (int64_t)chunk, ntri);
-    for (int64_t pw = p0; pw < p1; pw += 1024) {                // wave-uniform trip count
+    for (int64_t pw = p0; pw < p1; pw += BIN_THREADS) {                // wave-uniform trip count
         const int64_t p = pw + t;
         const uint2 r = p < p1 ? ranges[p] : make_uint2(RANGE_NONE_X, 0u);
         for_each_tile(unpack_box(r), (uint32_t)p, [&](const PixBox& b, uint32_t prim, int tx, int ty) {
@@ -1273,13 +1275,13 @@ static SetupArgs make_setup_args(const DeviceFrame& f) {
     return a;
 }
 
-// LDS binning geometry: G workgroups of 1024 threads, each owning `chunk` consecutive primitives.
+// LDS binning geometry: G workgroups of BIN_THREADS threads, each owning `chunk` consecutive primitives.
 BinPlan plan_binning(int64_t ntri, int ntiles) {
     BinPlan p{};
     p.lds_bytes = (size_t)ntiles * 4;
     const char* force = getenv("SWR_BIN_MODE");
     p.use_lds = p.lds_bytes <= 144 * 1024 && !(force && force[0] == 'a');   // 'atomic' forces the fallback
-    int64_t g = (ntri + 1023) / 1024;
+    int64_t g = (ntri + BIN_THREADS - 1) / BIN_THREADS;
     static const int gmax = getenv("SWR_BIN_G") ? atoi(getenv("SWR_BIN_G")) : 256;   // 1 per CU (measured best)
     if (g > gmax) g = gmax;
     if (g > 16 * COLSEG) g = 16 * COLSEG;
@@ -1307,7 +1309,7 @@ void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)k_fill_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        hipLaunchKernelGGL(k_setup_hist, dim3(f.plan.G), dim3(1024), f.plan.lds_bytes, s, a, f.bin_matrix,
+        hipLaunchKernelGGL(k_setup_hist, dim3(f.plan.G), dim3(BIN_THREADS), f.plan.lds_bytes, s, a, f.bin_matrix,
                            f.plan.chunk, ntiles);
         hipLaunchKernelGGL(k_colscan, dim3((ntiles + 15) / 16), dim3(256), 0, s, f.bin_matrix, f.plan.G, ntiles,
                            f.tile_count);
@@ -1328,7 +1330,7 @@ void launch_fill(const DeviceFrame& f, hipStream_t s) {
     if (f.ntri <= 0) return;
     const int ntiles = f.tg.tiles_x * f.tg.tiles_y;
     if (f.plan.use_lds) {
-        hipLaunchKernelGGL(k_fill_lds, dim3(f.plan.G), dim3(1024), f.plan.lds_bytes + 4096, s, f.ranges, f.ntri,
+        hipLaunchKernelGGL(k_fill_lds, dim3(f.plan.G), dim3(BIN_THREADS), f.plan.lds_bytes + 4 * BIN_THREADS, s, f.ranges, f.ntri,
                            f.bin_matrix, f.tile_count, f.tile_start, f.counters, f.host_counters, f.bins,
                            f.capacity, f.plan.chunk, ntiles,
                            f.tg.tiles_x, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);

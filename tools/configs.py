@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Timing sanity of the other BASELINE configs (cfg2/3/5) on one GPU; parity is in tests/."""
 import sys, time, json
-sys.path.insert(0, '.')
+sys.path.insert(0, '.')  # run from the repo root: python tools/configs.py
 import swr_amd
 S = swr_amd.scenes
 for name, scene, flags in (("cfg2 torus 6320 tris 1080p painter", S.cfg2_teapot_scale(), 0),

@@ -284,8 +284,14 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
                            ((uint32_t)o0 << GEOM_ORD_SHIFT) | ((uint32_t)o1 << (GEOM_ORD_SHIFT + 2)) |
                            ((uint32_t)o2 << (GEOM_ORD_SHIFT + 4));
 
-    // record stores: 2 x 16 B per lane (+ 2 for the rare non-small triangle)
-    {
+    // bbox ∩ band -> tiles.  Every covered pixel lies in [minx,maxx] x [S0.y,S2.y] (spans are
+    // integer interpolants between vertex x's, :467-494).
+    const int x0 = max(minx, 0), x1 = min(maxx, a.tg.width - 1);
+    const int y0 = max(s0y, a.tg.row_begin), y1 = min(s2y, a.tg.row_end - 1);
+    const bool binned = ok && x0 <= x1 && y0 <= y1;
+    // record stores: 2 x 16 B per lane (+ 2 for the rare non-small triangle) — only for triangles
+    // that reach a bin: nobody ever gathers the record of a triangle that misses this GPU's band
+    if (binned) {
         const uint32_t db = ((uint32_t)(ix[1] - ix[0]) & 0xFFFFu) | ((uint32_t)(iy[1] - iy[0]) << 16);
         const uint32_t dc = ((uint32_t)(ix[2] - ix[0]) & 0xFFFFu) | ((uint32_t)(iy[2] - iy[0]) << 16);
         int4* gp = reinterpret_cast<int4*>(a.geo + p);
@@ -297,11 +303,7 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
             fp[1] = make_int4(ix[2], iy[2], 0, 0);
         }
     }
-    // bbox ∩ band -> tiles.  Every covered pixel lies in [minx,maxx] x [S0.y,S2.y] (spans are
-    // integer interpolants between vertex x's, :467-494).
-    const int x0 = max(minx, 0), x1 = min(maxx, a.tg.width - 1);
-    const int y0 = max(s0y, a.tg.row_begin), y1 = min(s2y, a.tg.row_end - 1);
-    if (ok && x0 <= x1 && y0 <= y1)
+    if (binned)
         range = make_uint2((uint32_t)x0 | ((uint32_t)x1 << 16),
                            (uint32_t)(y0 - a.tg.row_begin) | ((uint32_t)(y1 - a.tg.row_begin) << 16));
     return range;

@@ -1,0 +1,109 @@
+"""C-ABI behaviour on a real device: misuse codes, the resident path's state machine, timing and
+pipelining toggles, independent contexts.  (Parity proper is in test_gpu_parity.py.)"""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_draw_before_upload_or_target(swr):
+    with swr.Context() as ctx:
+        with pytest.raises(swr.SwrError) as e:
+            ctx.draw(swr.scenes.identity(), 0)
+        assert e.value.code == -6                                   # SWR_ERR_NO_SCENE
+        s = swr.scenes.cfg1_triangle()
+        ctx.scene_upload(s.vertices, s.indices)
+        with pytest.raises(swr.SwrError) as e:
+            ctx.draw(s.transform, 0)
+        assert e.value.code == -6                                   # no target yet
+        ctx.target_set(64, 64)
+        ctx.draw(s.transform, 0)
+        assert (ctx.read_color()[..., 3] == 255).sum() > 0
+
+
+def test_bad_arguments(swr):
+    L = swr.load_library()
+    with swr.Context() as ctx:
+        with pytest.raises(swr.SwrError) as e:
+            ctx.target_set(64, 64, 16, 64)                          # row_begin not a multiple of the tile height
+        assert e.value.code == -1
+        with pytest.raises(swr.SwrError) as e:
+            ctx.target_set(64, 64, 0, 65)
+        assert e.value.code == -1
+        with pytest.raises(swr.SwrError) as e:
+            ctx.target_set(70000, 64)                               # > 65535
+        assert e.value.code == -1
+        s = swr.scenes.cfg1_triangle()
+        ctx.scene_upload(s.vertices, s.indices)
+        ctx.target_set(64, 64)
+        with pytest.raises(swr.SwrError) as e:
+            ctx.draw(s.transform, 1 << 9)                           # unknown flag bit
+        assert e.value.code == -1
+        assert L.swr_render(ctx._h, None) == -1
+        assert L.swr_context_create(None, None) == -1
+    assert L.swr_sync(None) == -1 and L.swr_draw(None, None, 0) == -1
+
+
+def test_timing_levels_and_totals(swr):
+    s = swr.scenes.random_soup(2000, 320, 200, 3, r_ndc=0.1, flags=1)
+    with swr.Context() as ctx:
+        ctx.scene_upload(s.vertices, s.indices)
+        ctx.target_set(320, 200)
+        for level in (1, 2):
+            ctx.timing_enable(level)
+            ctx.timing_reset()
+            for _ in range(70):                                     # more frames than the 64-deep event ring
+                ctx.draw(s.transform, 1)
+            sums, n = ctx.timing_totals()
+            assert n == 70 and sums["raster_ms"] > 0
+            assert (sums["setup_bin_ms"] > 0) == (level == 2)
+            assert ctx.timings()["tile_pairs"] > 0
+        ctx.timing_enable(0)
+
+
+def test_pipelining_toggle_gives_identical_images(swr, oracle):
+    s = swr.scenes.random_soup(3000, 400, 300, 17, r_ndc=0.08, flags=1)
+    imgs = []
+    with swr.Context() as ctx:
+        ctx.scene_upload(s.vertices, s.indices)
+        ctx.target_set(400, 300)
+        for on in (True, False, True):
+            ctx.pipeline_enable(on)
+            for _ in range(5):
+                ctx.draw(s.transform, 1)
+            imgs.append((ctx.read_color(), ctx.read_depth()))
+    rc, rd, _, _ = oracle.render_scene(s, oracle.TINV_PER_TRIANGLE)
+    for c, d in imgs:
+        assert np.array_equal(c, rc) and np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+
+
+def test_independent_contexts_and_reuse(swr, oracle):
+    a = swr.scenes.random_soup(800, 200, 160, 5, r_ndc=0.15, flags=1)
+    b = swr.scenes.cfg2_teapot_scale(240, 136)
+    ca, cb = swr.Context(), swr.Context()
+    try:
+        ca.scene_upload(a.vertices, a.indices); ca.target_set(200, 160)
+        cb.scene_upload(b.vertices, b.indices); cb.target_set(240, 136)
+        ca.draw(a.transform, 1); cb.draw(b.transform, 0)            # both in flight
+        ia, ib = (ca.read_color(), ca.read_depth()), (cb.read_color(), cb.read_depth())
+        # re-upload a different scene / size into the same context
+        ca.scene_upload(b.vertices, b.indices); ca.target_set(240, 136)
+        ca.draw(b.transform, 0)
+        ia2 = (ca.read_color(), ca.read_depth())
+    finally:
+        ca.close(); cb.close()
+    ra = oracle.render_scene(a, oracle.TINV_PER_TRIANGLE)
+    rb = oracle.render(b.vertices, b.indices, b.transform, 240, 136, oracle.TINV_PER_TRIANGLE)
+    assert np.array_equal(ia[0], ra[0]) and np.array_equal(ia[1].view(np.uint32), ra[1].view(np.uint32))
+    for got in (ib, ia2):
+        assert np.array_equal(got[0], rb[0]) and np.array_equal(got[1].view(np.uint32), rb[1].view(np.uint32))
+
+
+def test_many_context_create_destroy(swr):
+    s = swr.scenes.cfg1_triangle()
+    for _ in range(20):
+        with swr.Context() as ctx:
+            c, _ = ctx.render(s.vertices, s.indices, s.transform, 64, 64, 0)
+            assert (c[..., 3] == 255).sum() > 0

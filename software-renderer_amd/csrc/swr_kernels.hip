@@ -721,10 +721,17 @@ __device__ __forceinline__ float pull_f(int byte_addr, float v) {
 
 // VAR > 0: timing-only ablations selected with SWR_DEBUG_VARIANT (results invalid):
 //   1 = no LDS atomic, 2 = no pulls/maths/atomic, 3 = no dense loop, 4 = no row walk at all
+#ifndef SWR_RASTER_MIN_WAVES
+#define SWR_RASTER_MIN_WAVES 6
+#endif
 template <bool ZTEST, int VAR = 0>
-__global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
+__global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster(RasterArgs a) {
     constexpr int SUPER = 2;   // dense steps whose owner search is done together
     constexpr int UNIT = 4;    // consecutive pixels of one span handled by one lane of a dense step
+#ifndef SWR_ROWS
+#define SWR_ROWS 2
+#endif
+    constexpr int ROWS = SWR_ROWS;   // consecutive rows of a triangle pooled into one dealing round (<= 4)
     __shared__ uint32_t next_chunk;           // work-stealing cursor over the chunks of the sorted bin
     __shared__ float4 tabA[RASTER_THREADS];   // per triangle of the batch: t00, t01, t10, t11
     __shared__ float4 tabB[RASTER_THREADS];   //                            za, zb, zc, cf.y
@@ -820,38 +827,54 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
             const int ye = mine ? yb : 0;
             volatile uint32_t* mk = span_mark[tid >> 6];
             while (VAR != 4 && VAR != 10 && __any(y <= ye)) {
-                const bool act = y <= ye;
-                int lo = 0, hi = -1;
-                if (act) {
-                    row_span_small(t.ch, y, lo, hi);
-                    lo = max(lo, X0);
-                    hi = min(hi, X1);
+                // ROWS consecutive rows of every triangle feed one dealing round: more units per round
+                // = fuller dense steps (a partially filled step costs as much as a full one).
+                int nu[ROWS], packed[ROWS];
+                int nut = 0;
+#pragma unroll
+                for (int r = 0; r < ROWS; r++) {
+                    const int yr = y + r;
+                    const bool act = yr <= ye;
+                    int lo = 0, hi = -1;
+                    if (act) {
+                        row_span_small(t.ch, yr, lo, hi);
+                        lo = max(lo, X0);
+                        hi = min(hi, X1);
+                    }
+                    const int w = act ? max(hi - lo + 1, 0) : 0;
+                    nu[r] = (w + UNIT - 1) / UNIT;                 // units of this span
+                    nut += nu[r];
+                    // per-row word of the owner: tile-local row (5 bits), span start and end (6 + 6 bits),
+                    // lo - C.x (15 bits signed; small coordinates: (x+.5) - (cx+.5) == x - cx exactly)
+                    packed[r] = ((yr - Y0) & 31) | (((lo - X0) & 63) << 5) | (((hi - X0) & 63) << 11) |
+                                ((lo - t.cx) << 17);
                 }
-                const int w = act ? max(hi - lo + 1, 0) : 0;
-                const int nu = (w + UNIT - 1) / UNIT;              // units of this span
-                const int pin = wave_incl_add(nu);
-                const int pex = pin - nu;
-                const int T = __builtin_amdgcn_readlane(pin, 63);   // units of this row step
-                // per-row word of the owner: tile-local row (5 bits), span start and end (6 + 6 bits),
-                // lo - C.x (15 bits signed; small coordinates: (x+.5) - (cx+.5) == x - cx exactly)
-                const int packed = ((y - Y0) & 31) | (((lo - X0) & 63) << 5) | (((hi - X0) & 63) << 11) |
-                                   ((lo - t.cx) << 17);
-                if (VAR == 3) asm volatile("" ::"v"(packed));
+                const int pin = wave_incl_add(nut);
+                const int pex = pin - nut;
+                const int T = __builtin_amdgcn_readlane(pin, 63);   // units of this round
+                if (VAR == 3) asm volatile("" ::"v"(packed[0]), "v"(packed[ROWS - 1]));
                 // Owner search for SUPER dense steps at once: ONE tagged marker scatter (stale
                 // markers carry an older tag, so the strip is never re-zeroed), then the reads and
-                // two interleaved max-scans.  The scanned value is (first unit + 1) << 7 |
-                // (owner lane + 1); it is monotone in the slot.
+                // two interleaved max-scans.  A marker is tag << 8 | row << 6 | owner lane; the scanned
+                // value is (first unit of the span + 1) << 8 | row << 6 | lane — monotone in the slot.
                 int carry = 0;
                 for (int sbase = 0; VAR != 3 && sbase < T; sbase += 64 * SUPER) {
                     tag++;
-                    const int s0 = pex - sbase;
-                    if (nu > 0 && s0 >= 0 && s0 < 64 * SUPER) mk[s0] = ((uint32_t)tag << 7) | (uint32_t)(lane + 1);
+                    {
+                        int s0 = pex - sbase;
+#pragma unroll
+                        for (int r = 0; r < ROWS; r++) {
+                            if (nu[r] > 0 && s0 >= 0 && s0 < 64 * SUPER)
+                                mk[s0] = ((uint32_t)tag << 8) | (uint32_t)(r << 6) | (uint32_t)lane;
+                            s0 += nu[r];
+                        }
+                    }
                     int own[SUPER];
 #pragma unroll
                     for (int k = 0; k < SUPER; k++) {
                         const uint32_t v = mk[64 * k + lane];
                         const int start1 = sbase + 64 * k + lane + 1;
-                        own[k] = (v >> 7) == (uint32_t)tag ? (int)((start1 << 7) | (int)(v & 127u)) : 0;
+                        own[k] = (v >> 8) == (uint32_t)tag ? (int)((start1 << 8) | (int)(v & 255u)) : 0;
                     }
                     static_assert(SUPER == 2, "the interleaved scan handles two steps");
                     wave_incl_max2(own[0], own[1]);
@@ -864,11 +887,17 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
                     for (int k = 0; k < SUPER; k++) {
                         const int base = sbase + 64 * k;
                         if (base >= T) break;
-                        const int owner = (own[k] & 127) - 1;
+                        const int owner = own[k] & 63;
+                        const int orow = (own[k] >> 6) & 3;
                         const int j = base + lane;
-                        const int offu = j - ((own[k] >> 7) - 1);    // unit index inside the owner's span
-                        if (VAR == 2) { asm volatile("" ::"v"(owner), "v"(offu)); continue; }
-                        const int pk = pull_i(owner << 2, packed);
+                        const int offu = j - ((own[k] >> 8) - 1);    // unit index inside the owner's span
+                        if (VAR == 2) { asm volatile("" ::"v"(owner), "v"(offu), "v"(orow)); continue; }
+                        int pk = pull_i(owner << 2, packed[0]);
+#pragma unroll
+                        for (int r = 1; r < ROWS; r++) {
+                            const int pr = pull_i(owner << 2, packed[r]);
+                            pk = orow == r ? pr : pk;
+                        }
                         const uint32_t oprim = (uint32_t)pull_i(owner << 2, (int)t.prim);
                         float4 ta = make_float4(0, 0, 0, 0), tb = make_float4(0, 0, 0, 0);
                         if (ZTEST) { ta = tabA[wbase + owner]; tb = tabB[wbase + owner]; }
@@ -903,7 +932,7 @@ __global__ __launch_bounds__(RASTER_THREADS, 6) void k_raster(RasterArgs a) {
                         }
                     }
                 }
-                y++;
+                y += ROWS;
             }
         }
 

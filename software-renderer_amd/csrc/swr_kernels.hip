@@ -722,7 +722,7 @@ __device__ __forceinline__ float pull_f(int byte_addr, float v) {
 // VAR > 0: timing-only ablations selected with SWR_DEBUG_VARIANT (results invalid):
 //   1 = no LDS atomic, 2 = no pulls/maths/atomic, 3 = no dense loop, 4 = no row walk at all
 #ifndef SWR_RASTER_MIN_WAVES
-#define SWR_RASTER_MIN_WAVES 6
+#define SWR_RASTER_MIN_WAVES 5   // waves per SIMD the register allocator must allow (measured: 5 spill-free beats 6)
 #endif
 template <bool ZTEST, int VAR = 0>
 __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster(RasterArgs a) {
@@ -809,7 +809,57 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
             big = !t.ch.small || maxx - minx >= 16384 || (yb - ya + 1) * (bxb - bxa + 1) > BIG_AREA;
         }
 
-        // ---- phase 1: lane = triangle for the row walk, lane = 4-pixel unit for the pixel work --
+        // ---- big or huge-coordinate triangles first, one at a time, walked by the whole wave ----
+        // (done before the dense phase so that its per-triangle registers die early)
+        unsigned long long bigmask = __ballot(have && big);
+        while (bigmask) {
+            const int src = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)bigmask) - 1);
+            bigmask &= bigmask - 1;
+            TriState u;
+            u.ch.s0x = bcast_i(t.ch.s0x, src); u.ch.s0y = bcast_i(t.ch.s0y, src);
+            u.ch.s1x = bcast_i(t.ch.s1x, src); u.ch.s1y = bcast_i(t.ch.s1y, src);
+            u.ch.s2x = bcast_i(t.ch.s2x, src); u.ch.s2y = bcast_i(t.ch.s2y, src);
+            u.ch.r01 = bcast_f(t.ch.r01, src); u.ch.r12 = bcast_f(t.ch.r12, src);
+            u.ch.r02 = bcast_f(t.ch.r02, src);
+            u.ch.small = bcast_i(t.ch.small ? 1 : 0, src) != 0;
+            u.cfx = bcast_f(t.cfx, src); u.cfy = bcast_f(t.cfy, src);
+            u.t00 = bcast_f(t.t00, src); u.t01 = bcast_f(t.t01, src);
+            u.t10 = bcast_f(t.t10, src); u.t11 = bcast_f(t.t11, src);
+            u.za = bcast_f(t.za, src); u.zb = bcast_f(t.zb, src); u.zc = bcast_f(t.zc, src);
+            u.prim = (uint32_t)bcast_i((int)t.prim, src);
+            const int uya = bcast_i(ya, src), uyb = bcast_i(yb, src);
+
+            for (int yc = uya; yc <= uyb; yc += 64) {
+                // lane = row: each lane computes the span of one row of this 64-row chunk
+                const int yrow = yc + lane;
+                int lo = 0, hi = -1;
+                if (yrow <= uyb) {
+                    row_span(u.ch, yrow, lo, hi);
+                    lo = max(lo, X0);
+                    hi = min(hi, X1);
+                }
+                // chunk shape from the widest span: 16x4, 32x2 or 64x1 pixels per wave step
+                int wmax = hi - lo + 1;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off));
+                const int lw = wmax <= 16 ? 4 : (wmax <= 32 ? 5 : 6);
+                const int cw = 1 << lw, rows_per = 64 >> lw;
+                const int nrows = min(64, uyb - yc + 1);
+                for (int r0i = 0; r0i < nrows; r0i += rows_per) {
+                    const int r = r0i + (lane >> lw);
+                    const int rlo = __shfl(lo, r & 63), rhi = __shfl(hi, r & 63);
+                    const int y = yc + r;
+                    const bool rowok = r < nrows;
+                    const float dy = ((float)y + 0.5f) - u.cfy;
+                    const float q0 = u.t01 * dy, q1 = u.t11 * dy;
+                    const int rowbase = (y - Y0) * TILE_W - X0;
+                    if (rowok)
+                        for (int x = rlo + (lane & (cw - 1)); x <= rhi; x += cw)
+                            fragment<ZTEST>(keys, u, x, rowbase + x, q0, q1);
+                }
+            }
+        }
+        // ---- dense phase: lane = triangle for the row walk, lane = 4-pixel unit for the pixel work --
         // Every lane steps through the rows of ITS OWN (small) triangle.  Per row step each span is
         // cut into units of UNIT consecutive pixels; the unit counts are prefix-summed across the
         // wave and the units of all 64 spans are dealt out densely, one per lane.  The owner lane
@@ -910,7 +960,7 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
                             const float dx0 = (float)((pk >> 17) + UNIT * offu);
                             const float dy = ((float)(Y0 + yl) + 0.5f) - tb.w;   // (y + .5) - cf.y
                             const float r0 = ta.y * dy, r1 = ta.w * dy;          // t01*dy, t11*dy
-#pragma unroll
+#pragma unroll   // 4 pixels in flight: needs 86 VGPRs, hence 5 waves/SIMD (at 6 it spills; `unroll 2` at 6 waves was 2 % slower)
                             for (int q = 0; q < UNIT; q++) {
                                 const float dx = dx0 + (float)q;                 // exact: small integers
                                 const float w0 = ta.x * dx + r0;
@@ -936,55 +986,6 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
             }
         }
 
-        // ---- phase 2: big triangles, one at a time, walked by the whole wave ----------------
-        unsigned long long bigmask = __ballot(have && big);
-        while (bigmask) {
-            const int src = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)bigmask) - 1);
-            bigmask &= bigmask - 1;
-            TriState u;
-            u.ch.s0x = bcast_i(t.ch.s0x, src); u.ch.s0y = bcast_i(t.ch.s0y, src);
-            u.ch.s1x = bcast_i(t.ch.s1x, src); u.ch.s1y = bcast_i(t.ch.s1y, src);
-            u.ch.s2x = bcast_i(t.ch.s2x, src); u.ch.s2y = bcast_i(t.ch.s2y, src);
-            u.ch.r01 = bcast_f(t.ch.r01, src); u.ch.r12 = bcast_f(t.ch.r12, src);
-            u.ch.r02 = bcast_f(t.ch.r02, src);
-            u.ch.small = bcast_i(t.ch.small ? 1 : 0, src) != 0;
-            u.cfx = bcast_f(t.cfx, src); u.cfy = bcast_f(t.cfy, src);
-            u.t00 = bcast_f(t.t00, src); u.t01 = bcast_f(t.t01, src);
-            u.t10 = bcast_f(t.t10, src); u.t11 = bcast_f(t.t11, src);
-            u.za = bcast_f(t.za, src); u.zb = bcast_f(t.zb, src); u.zc = bcast_f(t.zc, src);
-            u.prim = (uint32_t)bcast_i((int)t.prim, src);
-            const int uya = bcast_i(ya, src), uyb = bcast_i(yb, src);
-
-            for (int yc = uya; yc <= uyb; yc += 64) {
-                // lane = row: each lane computes the span of one row of this 64-row chunk
-                const int yrow = yc + lane;
-                int lo = 0, hi = -1;
-                if (yrow <= uyb) {
-                    row_span(u.ch, yrow, lo, hi);
-                    lo = max(lo, X0);
-                    hi = min(hi, X1);
-                }
-                // chunk shape from the widest span: 16x4, 32x2 or 64x1 pixels per wave step
-                int wmax = hi - lo + 1;
-#pragma unroll
-                for (int off = 32; off > 0; off >>= 1) wmax = max(wmax, __shfl_xor(wmax, off));
-                const int lw = wmax <= 16 ? 4 : (wmax <= 32 ? 5 : 6);
-                const int cw = 1 << lw, rows_per = 64 >> lw;
-                const int nrows = min(64, uyb - yc + 1);
-                for (int r0i = 0; r0i < nrows; r0i += rows_per) {
-                    const int r = r0i + (lane >> lw);
-                    const int rlo = __shfl(lo, r & 63), rhi = __shfl(hi, r & 63);
-                    const int y = yc + r;
-                    const bool rowok = r < nrows;
-                    const float dy = ((float)y + 0.5f) - u.cfy;
-                    const float q0 = u.t01 * dy, q1 = u.t11 * dy;
-                    const int rowbase = (y - Y0) * TILE_W - X0;
-                    if (rowok)
-                        for (int x = rlo + (lane & (cw - 1)); x <= rhi; x += cw)
-                            fragment<ZTEST>(keys, u, x, rowbase + x, q0, q1);
-                }
-            }
-        }
         // steal the next chunk (wave-uniform)
         first_chunk = false;
         uint32_t nx = 0u;

@@ -32,7 +32,7 @@ struct swr_context {
     std::string err;
 
     // scene (RenderPass.vertices / .indices)
-    DevBuf vertices, indices, xyz, rgb, idx32;
+    DevBuf vertices, indices, xyz, rgb, idx32, tri_rgb;
     int64_t nv = 0, ni = 0;
     bool has_scene = false;
 
@@ -137,6 +137,7 @@ DeviceFrame make_frame(swr_context* c, int si, const float m[16], uint32_t flags
     f.xyz = (const float4*)c->xyz.p;
     f.rgb = (const float4*)c->rgb.p;
     f.idx32 = (const uint32_t*)c->idx32.p;
+    f.tri_rgb = (const float4*)c->tri_rgb.p;
     f.vertex_count = c->nv;
     f.ntri = c->ni / 3;
     f.geo = (GeomRec*)sl.geo.p;
@@ -324,7 +325,7 @@ void swr_context_destroy(swr_context* c) {
     hipSetDevice(c->device);
     if (c->bin_stream) hipStreamSynchronize(c->bin_stream);
     if (c->stream) hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->xyz, &c->rgb, &c->idx32, &c->color, &c->depth};
+    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->xyz, &c->rgb, &c->idx32, &c->tri_rgb, &c->color, &c->depth};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& sl : c->slot) {
         DevBuf* sb[] = {&sl.geo, &sl.geo_full, &sl.ranges, &sl.bins, &sl.bin_matrix, &sl.tilebuf};
@@ -358,6 +359,7 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     if ((rc = ensure(c, c->xyz, (size_t)vertex_count * 16))) return rc;
     if ((rc = ensure(c, c->rgb, (size_t)vertex_count * 16))) return rc;
     if ((rc = ensure(c, c->idx32, (size_t)index_count * 4))) return rc;
+    if ((rc = ensure(c, c->tri_rgb, (size_t)index_count * 16))) return rc;
     for (auto& sl : c->slot) {
         if ((rc = ensure(c, sl.geo, (size_t)(index_count / 3) * sizeof(GeomRec)))) return rc;
         if ((rc = ensure(c, sl.geo_full, (size_t)(index_count / 3) * sizeof(GeomFull)))) return rc;
@@ -373,7 +375,7 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     HIP_TRY(c, hipMemsetAsync(c->slot[0].tilebuf.p, 0, CNT_WORDS * 4, c->stream));
     launch_validate_indices((const int64_t*)c->indices.p, index_count, vertex_count, (uint32_t*)c->slot[0].tilebuf.p, c->stream);
     launch_split_scene((const swr_vertex*)c->vertices.p, vertex_count, (const int64_t*)c->indices.p, index_count,
-                       (float4*)c->xyz.p, (float4*)c->rgb.p, (uint32_t*)c->idx32.p, c->stream);
+                       (float4*)c->xyz.p, (float4*)c->rgb.p, (uint32_t*)c->idx32.p, (float4*)c->tri_rgb.p, c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->slot[0].tilebuf.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

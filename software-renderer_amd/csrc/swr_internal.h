@@ -66,6 +66,7 @@ struct DeviceFrame {
     const float4* xyz;             // [nv] split positions
     const float4* rgb;             // [nv] split colours
     const uint32_t* idx32;         // [ni] narrowed indices
+    const float4* tri_rgb;         // [ni] colours de-indexed per primitive corner (48 B / triangle)
     int64_t vertex_count;
     int64_t ntri;
     GeomRec* geo;
@@ -90,7 +91,7 @@ struct DeviceFrame {
 void launch_validate_indices(const int64_t* indices, int64_t count, int64_t vertex_count,
                              uint32_t* counters, hipStream_t s);
 void launch_split_scene(const swr_vertex* v, int64_t nv, const int64_t* idx, int64_t ni, float4* xyz,
-                        float4* rgb, uint32_t* idx32, hipStream_t s);
+                        float4* rgb, uint32_t* idx32, float4* tri_rgb, hipStream_t s);
 void launch_setup_bin(const DeviceFrame& f, hipStream_t s);
 void launch_scan(const DeviceFrame& f, hipStream_t s);
 void launch_fill(const DeviceFrame& f, hipStream_t s);

@@ -19,7 +19,7 @@
 //                                     ds_min_u64).  Resolve: key -> winning primitive -> barycentric
 //                                     colour -> fragment_shader -> one 16-B/lane framebuffer store per
 //                                     4 pixels (clear fused: HBM sees each pixel exactly once).
-//   k_raster_metal                  : the same frame under the Metal path's rules (SWR_FLAG_METAL_RULES)
+//   k_raster<.., METAL>             : the same frame under the Metal path's rules (SWR_FLAG_METAL_RULES)
 //   k_points / k_points_resolve     : PrimitiveType .vertices;  k_clear_band: .line (reference stub)
 //   k_split_scene, k_validate_indices: once per swr_scene_upload
 //
@@ -139,15 +139,21 @@ __global__ void k_validate_indices(const int64_t* __restrict__ idx, int64_t n, i
 // so the per-frame setup kernel streams 60 MB instead of 120 MB at 1 M triangles.
 __global__ void k_split_scene(const swr_vertex* __restrict__ v, int64_t nv, const int64_t* __restrict__ idx,
                               int64_t ni, float4* __restrict__ xyz, float4* __restrict__ rgb,
-                              uint32_t* __restrict__ idx32) {
+                              uint32_t* __restrict__ idx32, float4* __restrict__ tri_rgb) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const float4* vp = reinterpret_cast<const float4*>(v);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
         xyz[i] = vp[2 * i];
         rgb[i] = vp[2 * i + 1];
     }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ni; i += stride)
-        idx32[i] = (uint32_t)idx[i];
+    // tri_rgb: the three vertex colours of primitive p, de-indexed into one 48-byte record, so the
+    // resolve fetches them with one gather instead of idx32 -> rgb (two dependent levels, six lines).
+    // The index range is validated by k_validate_indices in the same upload; a bad index reads nothing.
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ni; i += stride) {
+        const int64_t ix = idx[i];
+        idx32[i] = (uint32_t)ix;
+        tri_rgb[i] = (ix >= 0 && ix < nv) ? vp[2 * ix + 1] : make_float4(0, 0, 0, 0);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -601,8 +607,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_bins(uint32_t* __restrict
 struct RasterArgs {
     const GeomRec* geo;
     const GeomFull* geo_full;
-    const float4* rgb;          // [nv] vertex colours
-    const uint32_t* idx32;      // [3*ntri]
+    const float4* tri_rgb;      // [3*ntri] vertex colours of each primitive, de-indexed at upload
     const uint32_t* tile_start;
     const uint32_t* bins;
     const uint32_t* counters;
@@ -677,6 +682,28 @@ __device__ __forceinline__ float bcast_f(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
 }
 
+struct MetalTri {
+    float p3x, p3y, A0, B0, A1, B1, divider, z0, z1, z2;
+};
+__device__ __forceinline__ void metal_consts(const int vx[3], const int vy[3], float za, float zb, float zc,
+                                             MetalTri& m) {
+    const float p1x = (float)vx[0], p1y = (float)vy[0], p2x = (float)vx[1], p2y = (float)vy[1];
+    m.p3x = (float)vx[2]; m.p3y = (float)vy[2];
+    m.divider = (p1x - m.p3x) * (p2y - m.p3y) - (p2x - m.p3x) * (p1y - m.p3y);   // :143
+    m.A0 = p2y - m.p3y; m.B0 = m.p3x - p2x;                                       // :144
+    m.A1 = m.p3y - p1y; m.B1 = p1x - m.p3x;                                       // :147
+    m.z0 = za; m.z1 = zb; m.z2 = zc;
+}
+__device__ __forceinline__ bool metal_weights(const MetalTri& m, int x, int y, float& w0, float& w1, float& w2) {
+    const float sx = (float)x + 0.5f, sy = (float)y + 0.5f;                       // :133
+    w0 = m.A0 * (sx - m.p3x) + m.B0 * (sy - m.p3y);
+    w0 = w0 / m.divider;                                                          // :145
+    w1 = m.A1 * (sx - m.p3x) + m.B1 * (sy - m.p3y);
+    w1 = w1 / m.divider;                                                          // :148
+    w2 = 1.0f - w0 - w1;                                                          // :149
+    return 0.0f <= w0 && w0 <= 1.0f && 0.0f <= w1 && w1 <= 1.0f && 0.0f <= w2 && w2 <= 1.0f;   // :153
+}
+
 // ---- wave64 scans on DPP (all 64 lanes must be active) ---------------------------------------
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ int dpp0(int v) {
@@ -724,8 +751,12 @@ __device__ __forceinline__ float pull_f(int byte_addr, float v) {
 #ifndef SWR_RASTER_MIN_WAVES
 #define SWR_RASTER_MIN_WAVES 5   // waves per SIMD the register allocator must allow (measured: 5 spill-free beats 6)
 #endif
-template <bool ZTEST, int VAR = 0>
+// METAL = the Metal path's rules (SWR_FLAG_METAL_RULES; Shaders.metal:123-167) on the same machinery:
+// the "span" of every row of the ROI is the ROI's x-range, the per-pixel maths is the `divider`
+// barycentric with the inside test, the store is bgra8Unorm.
+template <bool ZTEST, int VAR = 0, bool METAL = false>
 __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster(RasterArgs a) {
+    static_assert(!METAL || ZTEST, "the Metal rules always z-test");
     constexpr int SUPER = 2;   // dense steps whose owner search is done together
     constexpr int UNIT = 4;    // consecutive pixels of one span handled by one lane of a dense step
 #ifndef SWR_ROWS
@@ -799,7 +830,25 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
                 q0 = reinterpret_cast<const int4*>(a.geo + prim)[0];
                 q1 = reinterpret_cast<const float4*>(a.geo + prim)[1];
             }
-            load_tri(a.geo_full, prim, q0, q1, t, minx, maxx);
+            if (METAL) {
+                // TriState re-used: t00..t11 = A0,B0,A1,B1 of the `divider` formula, cf.y = p3.y, cx = p3.x,
+                // ch.s0 / ch.s2 = ROI min / max corner
+                int vx[3], vy[3];
+                decode_vertices(a.geo_full, prim, q0, q1, vx, vy);
+                MetalTri mt;
+                metal_consts(vx, vy, q1.x, q1.y, q1.z, mt);
+                t.t00 = mt.A0; t.t01 = mt.B0; t.t10 = mt.A1; t.t11 = mt.B1;
+                t.za = mt.z0; t.zb = mt.z1; t.zc = mt.z2;
+                t.cfx = mt.p3x; t.cfy = mt.p3y; t.cx = vx[2];
+                t.prim = prim;
+                t.ch.small = (__float_as_uint(q1.w) & GEOM_SMALL) != 0;
+                minx = min(vx[0], min(vx[1], vx[2])); maxx = max(vx[0], max(vx[1], vx[2]));
+                t.ch.s0x = minx; t.ch.s2x = maxx;
+                t.ch.s0y = min(vy[0], min(vy[1], vy[2])); t.ch.s2y = max(vy[0], max(vy[1], vy[2]));
+                t.ch.s1x = t.ch.s1y = 0; t.ch.r01 = t.ch.r12 = t.ch.r02 = 0.0f;
+            } else {
+                load_tri(a.geo_full, prim, q0, q1, t, minx, maxx);
+            }
             ya = max(t.ch.s0y, Y0);
             yb = min(t.ch.s2y, Y1);
             bxa = max(minx, X0);
@@ -815,6 +864,37 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
         while (bigmask) {
             const int src = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)bigmask) - 1);
             bigmask &= bigmask - 1;
+            if (METAL) {
+                // ROI ∩ tile of one huge-coordinate triangle, lanes = pixels of a 16x4 / 32x2 / 64x1 chunk
+                MetalTri mt;
+                mt.A0 = bcast_f(t.t00, src); mt.B0 = bcast_f(t.t01, src);
+                mt.A1 = bcast_f(t.t10, src); mt.B1 = bcast_f(t.t11, src);
+                mt.z0 = bcast_f(t.za, src); mt.z1 = bcast_f(t.zb, src); mt.z2 = bcast_f(t.zc, src);
+                mt.p3x = bcast_f(t.cfx, src); mt.p3y = bcast_f(t.cfy, src);
+                mt.divider = mt.B1 * mt.A0 - mt.B0 * mt.A1;      // == (p1-p3)x(p2-p3): same products, same rounding
+                const uint32_t uprim = (uint32_t)bcast_i((int)t.prim, src);
+                const int xa = max(bcast_i(t.ch.s0x, src), X0), xb = min(bcast_i(t.ch.s2x, src), X1);
+                const int uya = bcast_i(ya, src), uyb = bcast_i(yb, src);
+                if (xa > xb) continue;
+                const int w = xb - xa + 1;
+                const int lw = w <= 16 ? 4 : (w <= 32 ? 5 : 6);
+                const int cw = 1 << lw, rows_per = 64 >> lw;
+                for (int yr = uya; yr <= uyb; yr += rows_per) {
+                    const int y = yr + (lane >> lw);
+                    for (int x = xa + (lane & (cw - 1)); x <= xb; x += cw) {
+                        float w0, w1, w2;
+                        if (y <= uyb && metal_weights(mt, x, y, w0, w1, w2)) {
+                            float z = w0 * mt.z0 + w1 * mt.z1 + w2 * mt.z2;
+                            if (z < INFINITY) {
+                                z = z + 0.0f;
+                                atomicMin(&keys[(y - Y0) * TILE_W + (x - X0)],
+                                          ((unsigned long long)orderable_depth(z) << 32) | (unsigned long long)uprim);
+                            }
+                        }
+                    }
+                }
+                continue;
+            }
             TriState u;
             u.ch.s0x = bcast_i(t.ch.s0x, src); u.ch.s0y = bcast_i(t.ch.s0y, src);
             u.ch.s1x = bcast_i(t.ch.s1x, src); u.ch.s1y = bcast_i(t.ch.s1y, src);
@@ -887,7 +967,8 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
                     const bool act = yr <= ye;
                     int lo = 0, hi = -1;
                     if (act) {
-                        row_span_small(t.ch, yr, lo, hi);
+                        if (METAL) { lo = t.ch.s0x; hi = t.ch.s2x; }      // every ROI row spans the ROI's x-range
+                        else row_span_small(t.ch, yr, lo, hi);
                         lo = max(lo, X0);
                         hi = min(hi, X1);
                     }
@@ -956,7 +1037,30 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
                         const int nvalid = j < T ? ((pk >> 11) & 63) - xl0 + 1 : 0;   // pixels left in the span
                         const int lidx0 = yl * TILE_W + xl0;
                         if (VAR == 5) { asm volatile("" ::"v"(ta.x), "v"(ta.y), "v"(ta.z), "v"(ta.w), "v"(tb.x), "v"(tb.y), "v"(tb.z), "v"(tb.w), "v"(nvalid), "v"(lidx0), "v"(oprim)); continue; }
-                        if (ZTEST) {
+                        if (METAL) {
+                            // Shaders.metal:133-161 with ta = (A0,B0,A1,B1), tb = (z1,z2,z3, p3.y)
+                            const float dxp0 = (float)((pk >> 17) + UNIT * offu) + 0.5f;   // (x + .5) - p3.x, exact
+                            const float dyp = ((float)(Y0 + yl) + 0.5f) - tb.w;            // (y + .5) - p3.y
+                            const float divider = ta.w * ta.x - ta.y * ta.z;               // :143
+                            const float n0 = ta.y * dyp, n1 = ta.w * dyp;
+#pragma unroll
+                            for (int q = 0; q < UNIT; q++) {
+                                const float dxp = dxp0 + (float)q;
+                                float w0 = ta.x * dxp + n0;                                // :144
+                                w0 = w0 / divider;                                         // :145
+                                float w1 = ta.z * dxp + n1;                                // :147
+                                w1 = w1 / divider;                                         // :148
+                                const float w2 = 1.0f - w0 - w1;                           // :149
+                                const bool inside = 0.0f <= w0 && w0 <= 1.0f && 0.0f <= w1 && w1 <= 1.0f &&
+                                                    0.0f <= w2 && w2 <= 1.0f;              // :153
+                                float d = w0 * tb.x + w1 * tb.y + w2 * tb.z;               // :157,:159
+                                const bool live = q < nvalid && inside && d < INFINITY;
+                                d = d + 0.0f;
+                                const unsigned long long key =
+                                    ((unsigned long long)orderable_depth(d) << 32) | (unsigned long long)oprim;
+                                if (live) atomicMin(&keys[lidx0 + q], key);
+                            }
+                        } else if (ZTEST) {
                             const float dx0 = (float)((pk >> 17) + UNIT * offu);
                             const float dy = ((float)(Y0 + yl) + 0.5f) - tb.w;   // (y + .5) - cf.y
                             const float r0 = ta.y * dy, r1 = ta.w * dy;          // t01*dy, t11*dy
@@ -1009,6 +1113,7 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
         uint32_t cached_prim = 0xFFFFFFFFu;
         float4 q2 = make_float4(0, 0, 0, 0), q3 = q2, ca = q2, cb = q2, cc = q2;
         float cfx = 0.0f, cfy = 0.0f;
+        MetalTri mt = {};
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const unsigned long long key = keys[ly * TILE_W + lx + k];
@@ -1028,22 +1133,31 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
                         int4 g0;
                         int vx[3], vy[3];
                         load_vertices(a.geo, a.geo_full, prim, g0, q3, vx, vy);
-                        // T() of the winning primitive, recomputed (same expressions, same bits)
-                        tinv_of(vx[0], vy[0], vx[1], vy[1], vx[2], vy[2], q2.x, q2.y, q2.z, q2.w);
-                        cfx = (float)vx[2] + 0.5f;
-                        cfy = (float)vy[2] + 0.5f;
+                        if (METAL) {
+                            metal_consts(vx, vy, q3.x, q3.y, q3.z, mt);
+                        } else {
+                            // T() of the winning primitive, recomputed (same expressions, same bits)
+                            tinv_of(vx[0], vy[0], vx[1], vy[1], vx[2], vy[2], q2.x, q2.y, q2.z, q2.w);
+                            cfx = (float)vx[2] + 0.5f;
+                            cfy = (float)vy[2] + 0.5f;
+                        }
                         if (want_color) {
-                            // vertex colours of a,b,c through the index buffer (RenderPass.indices / .vertices)
-                            ca = a.rgb[a.idx32[3 * (size_t)prim + 0]];
-                            cb = a.rgb[a.idx32[3 * (size_t)prim + 1]];
-                            cc = a.rgb[a.idx32[3 * (size_t)prim + 2]];
+                            // vertex colours of a,b,c (RenderPass.vertices[RenderPass.indices[3p+k]].color), one 48-B record
+                            ca = a.tri_rgb[3 * (size_t)prim + 0];
+                            cb = a.tri_rgb[3 * (size_t)prim + 1];
+                            cc = a.tri_rgb[3 * (size_t)prim + 2];
                         }
                     }
-                    const float dx = ((float)(x + k) + 0.5f) - cfx;
-                    const float dy = ((float)y + 0.5f) - cfy;
-                    const float w0 = q2.x * dx + q2.y * dy;
-                    const float w1 = q2.z * dx + q2.w * dy;
-                    const float w2 = 1.0f - w0 - w1;
+                    float w0, w1, w2;
+                    if (METAL) {
+                        metal_weights(mt, x + k, y, w0, w1, w2);          // Shaders.metal:133-149
+                    } else {
+                        const float dx = ((float)(x + k) + 0.5f) - cfx;
+                        const float dy = ((float)y + 0.5f) - cfy;
+                        w0 = q2.x * dx + q2.y * dy;
+                        w1 = q2.z * dx + q2.w * dy;
+                        w2 = 1.0f - w0 - w1;
+                    }
                     if (ZTEST) d = q3.x * w0 + q3.y * w1 + q3.z * w2;
                     if (want_color) {
                         VertexOut vin;
@@ -1052,12 +1166,12 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
                                                 ca.y * w0 + cb.y * w1 + cc.y * w2,
                                                 ca.z * w0 + cb.z * w1 + cc.z * w2);
                         const float4 f = fragment_shader(vin);
-                        // Pixel(float3:) -> .floats(b: z, g: y, r: x, a: 1) (:116-128)
-                        const uint32_t qb = (uint32_t)(fminf(fmaxf(f.z, 0.0f), 1.0f) * 255.0f);
-                        const uint32_t qg = (uint32_t)(fminf(fmaxf(f.y, 0.0f), 1.0f) * 255.0f);
-                        const uint32_t qr = (uint32_t)(fminf(fmaxf(f.x, 0.0f), 1.0f) * 255.0f);
-                        const uint32_t qa = (uint32_t)(fminf(fmaxf(f.w, 0.0f), 1.0f) * 255.0f);
-                        c = qb | (qg << 8) | (qr << 16) | (qa << 24);
+                        // Pixel(float3:) -> .floats(b: z, g: y, r: x, a: 1) truncates (:116-128);
+                        // the Metal path's bgra8Unorm store rounds to nearest even
+                        float ub = fminf(fmaxf(f.z, 0.0f), 1.0f) * 255.0f, ug = fminf(fmaxf(f.y, 0.0f), 1.0f) * 255.0f;
+                        float ur = fminf(fmaxf(f.x, 0.0f), 1.0f) * 255.0f, ua = fminf(fmaxf(f.w, 0.0f), 1.0f) * 255.0f;
+                        if (METAL) { ub = rintf(ub); ug = rintf(ug); ur = rintf(ur); ua = rintf(ua); }
+                        c = (uint32_t)ub | ((uint32_t)ug << 8) | ((uint32_t)ur << 16) | ((uint32_t)ua << 24);
                     }
                 }
             }
@@ -1075,138 +1189,6 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
                 a.depth[at + k] = dpix[k];
             }
         }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// k_raster_metal: the Metal path's rules (SWR_FLAG_METAL_RULES; Shaders.metal:123-167) on the same
-// binning, LDS key tiles and visibility keys.  One thread per pixel of the triangle's ROI (here:
-// ROI ∩ tile), sample at +0.5, barycentrics by the `divider` formula, inside = all(0 <= ws <= 1),
-// strict '<' z-test in primitive order (= min depth, ties -> lowest index), colour through
-// fragment_shader and a bgra8Unorm store.  First version: each wave takes one triangle at a time
-// (readlane broadcast) and spreads the ROI rows over its lanes in 16x4 / 32x2 / 64x1 chunks.
-// ------------------------------------------------------------------------------------------
-struct MetalTri {
-    float p3x, p3y, A0, B0, A1, B1, divider, z0, z1, z2;
-};
-__device__ __forceinline__ void metal_consts(const int vx[3], const int vy[3], float za, float zb, float zc,
-                                             MetalTri& m) {
-    const float p1x = (float)vx[0], p1y = (float)vy[0], p2x = (float)vx[1], p2y = (float)vy[1];
-    m.p3x = (float)vx[2]; m.p3y = (float)vy[2];
-    m.divider = (p1x - m.p3x) * (p2y - m.p3y) - (p2x - m.p3x) * (p1y - m.p3y);   // :143
-    m.A0 = p2y - m.p3y; m.B0 = m.p3x - p2x;                                       // :144
-    m.A1 = m.p3y - p1y; m.B1 = p1x - m.p3x;                                       // :147
-    m.z0 = za; m.z1 = zb; m.z2 = zc;
-}
-__device__ __forceinline__ bool metal_weights(const MetalTri& m, int x, int y, float& w0, float& w1, float& w2) {
-    const float sx = (float)x + 0.5f, sy = (float)y + 0.5f;                       // :133
-    w0 = m.A0 * (sx - m.p3x) + m.B0 * (sy - m.p3y);
-    w0 = w0 / m.divider;                                                          // :145
-    w1 = m.A1 * (sx - m.p3x) + m.B1 * (sy - m.p3y);
-    w1 = w1 / m.divider;                                                          // :148
-    w2 = 1.0f - w0 - w1;                                                          // :149
-    return 0.0f <= w0 && w0 <= 1.0f && 0.0f <= w1 && w1 <= 1.0f && 0.0f <= w2 && w2 <= 1.0f;   // :153
-}
-
-__global__ __launch_bounds__(RASTER_THREADS) void k_raster_metal(RasterArgs a) {
-    __shared__ unsigned long long keys[TILE_W * TILE_H];
-    const int tile = blockIdx.x;
-    const int tx = tile % a.tg.tiles_x, ty = tile / a.tg.tiles_x;
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int X0 = tx * TILE_W, Y0 = a.tg.row_begin + ty * TILE_H;
-    const int X1 = min(X0 + TILE_W, a.tg.width) - 1;
-    const int Y1 = min(Y0 + TILE_H, a.tg.row_end) - 1;
-    for (int i = tid; i < TILE_W * TILE_H; i += RASTER_THREADS) keys[i] = KEY_EMPTY;   // fused clear
-    __syncthreads();
-    const bool overflow = a.counters[CNT_PAIRS] > a.capacity;
-    const uint32_t b0 = overflow ? 0u : a.tile_start[tile];
-    const uint32_t b1 = overflow ? 0u : a.tile_start[tile + 1];
-    const uint32_t m = b1 - b0;
-    for (uint32_t base0 = 0; base0 < m; base0 += RASTER_THREADS) {
-        const uint32_t e = base0 + tid;
-        const bool have = e < m;
-        int vx[3] = {0, 0, 0}, vy[3] = {0, 0, 0};
-        float za = 0, zb = 0, zc = 0;
-        uint32_t prim = 0;
-        if (have) {
-            prim = a.bins[b0 + e];
-            int4 q0; float4 q1;
-            load_vertices(a.geo, a.geo_full, prim, q0, q1, vx, vy);
-            za = q1.x; zb = q1.y; zc = q1.z;
-        }
-        unsigned long long todo = __ballot(have);
-        while (todo) {
-            const int src = __builtin_amdgcn_readfirstlane((int)__ffsll((long long)todo) - 1);
-            todo &= todo - 1;
-            int ux[3], uy[3];
-#pragma unroll
-            for (int k = 0; k < 3; k++) { ux[k] = bcast_i(vx[k], src); uy[k] = bcast_i(vy[k], src); }
-            MetalTri mt;
-            metal_consts(ux, uy, bcast_f(za, src), bcast_f(zb, src), bcast_f(zc, src), mt);
-            const uint32_t uprim = (uint32_t)bcast_i((int)prim, src);
-            const int xa = max(min(ux[0], min(ux[1], ux[2])), X0), xb = min(max(ux[0], max(ux[1], ux[2])), X1);
-            const int ya = max(min(uy[0], min(uy[1], uy[2])), Y0), yb = min(max(uy[0], max(uy[1], uy[2])), Y1);
-            if (xa > xb || ya > yb) continue;
-            const int w = xb - xa + 1;
-            const int lw = w <= 16 ? 4 : (w <= 32 ? 5 : 6);
-            const int cw = 1 << lw, rows_per = 64 >> lw;
-            for (int yr = ya; yr <= yb; yr += rows_per) {
-                const int y = yr + (lane >> lw);
-                for (int x = xa + (lane & (cw - 1)); x <= xb; x += cw) {
-                    float w0, w1, w2;
-                    if (y <= yb && metal_weights(mt, x, y, w0, w1, w2)) {
-                        float z = w0 * mt.z0 + w1 * mt.z1 + w2 * mt.z2;                   // :157,:159
-                        if (z < INFINITY) {                                               // can pass :161 at all
-                            z = z + 0.0f;
-                            atomicMin(&keys[(y - Y0) * TILE_W + (x - X0)],
-                                      ((unsigned long long)orderable_depth(z) << 32) | (unsigned long long)uprim);
-                        }
-                    }
-                }
-            }
-        }
-    }
-    __syncthreads();
-    // resolve: winner -> same weights -> z, colour (fragment_shader) -> bgra8Unorm (round to nearest even)
-    const bool want_color = a.color != nullptr;
-    const int W = a.tg.width;
-    for (int i = tid; i < TILE_W * TILE_H; i += RASTER_THREADS) {
-        const int ly = i / TILE_W, lx = i % TILE_W;
-        const int y = Y0 + ly, x = X0 + lx;
-        if (y > Y1 || x > X1) continue;
-        const unsigned long long key = keys[i];
-        uint32_t c = 0u;
-        float d = INFINITY;
-        if (key != KEY_EMPTY) {
-            const uint32_t prim = (uint32_t)key;
-            int4 q0; float4 q1;
-            int vx[3], vy[3];
-            load_vertices(a.geo, a.geo_full, prim, q0, q1, vx, vy);
-            MetalTri mt;
-            metal_consts(vx, vy, q1.x, q1.y, q1.z, mt);
-            float w0, w1, w2;
-            metal_weights(mt, x, y, w0, w1, w2);
-            d = w0 * mt.z0 + w1 * mt.z1 + w2 * mt.z2;
-            if (want_color) {
-                const float4 ca = a.rgb[a.idx32[3 * (size_t)prim + 0]];
-                const float4 cb = a.rgb[a.idx32[3 * (size_t)prim + 1]];
-                const float4 cc = a.rgb[a.idx32[3 * (size_t)prim + 2]];
-                VertexOut vin;
-                vin.pos = make_float4((float)x + 0.5f, (float)y + 0.5f, d, 1.0f);
-                vin.color = make_float3(w0 * ca.x + w1 * cb.x + w2 * cc.x,              // :162
-                                        w0 * ca.y + w1 * cb.y + w2 * cc.y,
-                                        w0 * ca.z + w1 * cb.z + w2 * cc.z);
-                const float4 f = fragment_shader(vin);                                    // :163
-                const uint32_t qb = (uint32_t)rintf(fminf(fmaxf(f.z, 0.0f), 1.0f) * 255.0f);
-                const uint32_t qg = (uint32_t)rintf(fminf(fmaxf(f.y, 0.0f), 1.0f) * 255.0f);
-                const uint32_t qr = (uint32_t)rintf(fminf(fmaxf(f.x, 0.0f), 1.0f) * 255.0f);
-                const uint32_t qa = (uint32_t)rintf(fminf(fmaxf(f.w, 0.0f), 1.0f) * 255.0f);
-                c = qb | (qg << 8) | (qr << 16) | (qa << 24);
-            }
-        }
-        const size_t at = (size_t)(y - a.tg.row_begin) * (size_t)W + (size_t)x;
-        if (want_color) reinterpret_cast<uint32_t*>(a.color)[at] = c;
-        a.depth[at] = d;
     }
 }
 
@@ -1325,9 +1307,9 @@ BinPlan plan_binning(int64_t ntri, int ntiles) {
 }
 
 void launch_split_scene(const swr_vertex* v, int64_t nv, const int64_t* idx, int64_t ni, float4* xyz,
-                        float4* rgb, uint32_t* idx32, hipStream_t s) {
+                        float4* rgb, uint32_t* idx32, float4* tri_rgb, hipStream_t s) {
     if (nv <= 0 && ni <= 0) return;
-    hipLaunchKernelGGL(k_split_scene, dim3(2048), dim3(256), 0, s, v, nv, idx, ni, xyz, rgb, idx32);
+    hipLaunchKernelGGL(k_split_scene, dim3(2048), dim3(256), 0, s, v, nv, idx, ni, xyz, rgb, idx32, tri_rgb);
 }
 
 void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
@@ -1382,7 +1364,7 @@ void launch_sort_bins(const DeviceFrame& f, hipStream_t s) {
 
 void launch_raster(const DeviceFrame& f, hipStream_t s) {
     RasterArgs a;
-    a.geo = f.geo; a.geo_full = f.geo_full; a.rgb = f.rgb; a.idx32 = f.idx32;
+    a.geo = f.geo; a.geo_full = f.geo_full; a.tri_rgb = f.tri_rgb;
     a.tile_start = f.tile_start; a.bins = f.bins;
     a.counters = f.counters; a.capacity = f.capacity;
     a.color = (f.flags & SWR_FLAG_NO_COLOR) ? nullptr : f.color;
@@ -1391,7 +1373,7 @@ void launch_raster(const DeviceFrame& f, hipStream_t s) {
     const unsigned tiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
     if (tiles == 0) return;
     if (f.flags & SWR_FLAG_METAL_RULES) {
-        hipLaunchKernelGGL(k_raster_metal, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        hipLaunchKernelGGL((k_raster<true, 0, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         return;
     }
     static const int variant = getenv("SWR_DEBUG_VARIANT") ? atoi(getenv("SWR_DEBUG_VARIANT")) : 0;

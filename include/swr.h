@@ -21,7 +21,7 @@
 extern "C" {
 #endif
 
-#define SWR_ABI_VERSION 1
+#define SWR_ABI_VERSION 2
 
 /* ---- status codes (the reference has no error channel: it fatalError()s / try!s,
  *      Renderer.swift:26,209,239,497; GpuRenderer.swift:20-31,37-38) ------------------ */
@@ -67,6 +67,37 @@ typedef struct swr_vertex {
     float color[4];  /* r,g,b, lane 3 = padding (ignored) */
 } swr_vertex;        /* 32 bytes */
 
+/* ---- fragment-stage extensions (BASELINE configs 3 and 5) -------------------
+ * The reference's fragment stage returns the interpolated vertex colour (Shaders.metal:116-121) and has
+ * no normals, texture coordinates, lights or textures.  These additions sit behind the same
+ * fragment_shader(VertexOut) hook: VertexOut gains `normal` and `uv` varyings, interpolated exactly like
+ * `color` (screen-affine barycentric weights, Renderer.swift:266 / Shaders.metal:162), and the hook
+ * evaluates a Blinn-Phong model per pixel.  Every operation is a single IEEE binary32 + - * / sqrt in a
+ * fixed order, so the CPU oracle and the HIP kernels agree bit for bit; parity for these
+ * modes is build-internal (there is nothing in the reference to compare with). */
+typedef struct swr_vertex_attr {
+    float normal[4]; /* nx,ny,nz (any length; normalised per pixel), lane 3 = padding */
+    float uv[4];     /* u,v (repeat addressing), lanes 2,3 = padding */
+} swr_vertex_attr;   /* 32 bytes, parallel to swr_vertex: attribute i belongs to vertex i */
+
+enum {
+    SWR_SHADER_PASSTHROUGH = 0,    /* float4(vin.color, 1)                      (Shaders.metal:116-121) */
+    SWR_SHADER_PHONG = 1,          /* base = vin.color                          (BASELINE config 3)     */
+    SWR_SHADER_TEXTURED_PHONG = 2  /* base = vin.color * bilinear(texture, uv)  (BASELINE config 5)     */
+};
+
+/* rgb = base * (ambient + diffuse * max(N.L, 0)) + specular * max(N.H, 0)^(2^shininess_log2),  a = 1,
+ * N = vin.normal / |vin.normal| (zero vector when the length is 0).  light_dir and half_dir are given by
+ * the caller in the space of the normals (object space: normals are passed through untransformed, like
+ * colours, Shaders.metal:53); half_dir is the Blinn half vector of a distant light and viewer. */
+typedef struct swr_material {
+    int32_t shader;          /* SWR_SHADER_* */
+    int32_t shininess_log2;  /* 0..16: the exponent is a power of two, evaluated by repeated squaring */
+    float   light_dir[4];    /* unit vector towards the light, lane 3 ignored */
+    float   half_dir[4];     /* unit half vector, lane 3 ignored */
+    float   ambient, diffuse, specular, reserved;
+} swr_material;              /* 56 bytes */
+
 /* ---- RenderPass (Renderer.swift:191-200) + Image<T> (Renderer.swift:8-21) ------------
  * color: Pixel = {b,g,r,a} u8 (Renderer.swift:44-49); element (x,y) at color[y*width+x]
  * (App.swift:351-360: addressing uses width; bytesPerRow is stored but never read, so
@@ -86,6 +117,11 @@ typedef struct swr_render_pass {
     uint32_t flags;                 /* SWR_FLAG_* */
     float    transform[16];         /* matrix_float4x4, column-major: column c = transform[4c..4c+3]
                                        (Renderer.swift:199) */
+    /* extensions (all optional; NULL = the reference's passthrough fragment stage) */
+    const swr_vertex_attr* attributes;  /* vertex_count entries */
+    const swr_material*    material;
+    const void*            texture;     /* tex_width*tex_height Pixels (b,g,r,a), row-major; SWR_SHADER_TEXTURED_PHONG */
+    int32_t  tex_width, tex_height;
 } swr_render_pass;
 
 typedef struct swr_config {
@@ -132,6 +168,15 @@ int swr_render(swr_context* ctx, const swr_render_pass* pass);
  * makeBuffer / setBytes uploads of GpuRenderer.swift:68-71,93-103.  Validates indices. */
 int swr_scene_upload(swr_context* ctx, const swr_vertex* vertices, int64_t vertex_count,
                      const int64_t* indices, int64_t index_count);
+
+/* Fragment-stage extensions on the resident path.  swr_scene_attributes must follow the swr_scene_upload
+ * it belongs to (vertex_count must match; a new swr_scene_upload discards the attributes).  The material
+ * and the texture persist on the context until replaced; swr_material_set(ctx, NULL) restores the
+ * reference's passthrough stage.  A draw with a Phong material but no attributes, or a textured material
+ * but no texture, returns SWR_ERR_BAD_ARG. */
+int swr_scene_attributes(swr_context* ctx, const swr_vertex_attr* attributes, int64_t vertex_count);
+int swr_material_set(swr_context* ctx, const swr_material* material);
+int swr_texture_upload(swr_context* ctx, const void* bgra8, int32_t width, int32_t height);
 
 /* colorBuffer / depthBuffer size (Renderer.swift:192-193).  row_begin/row_end select the
  * tile-row band [row_begin,row_end) of the framebuffer this context (GPU) owns; pass

@@ -25,6 +25,32 @@ class Stats(ctypes.Structure):
                 ("triangles_drawn", ctypes.c_int64), ("triangles_skipped", ctypes.c_int64)]
 
 
+class Material(ctypes.Structure):
+    _fields_ = [("shader", ctypes.c_int32), ("shininess_log2", ctypes.c_int32),
+                ("light_dir", ctypes.c_float * 4), ("half_dir", ctypes.c_float * 4),
+                ("ambient", ctypes.c_float), ("diffuse", ctypes.c_float), ("specular", ctypes.c_float),
+                ("reserved", ctypes.c_float)]
+
+
+class ShadingC(ctypes.Structure):
+    _fields_ = [("attrs", ctypes.c_void_p), ("material", Material), ("texture", ctypes.c_void_p),
+                ("tex_w", ctypes.c_int32), ("tex_h", ctypes.c_int32)]
+
+
+def _shading_c(shading):
+    """swro_shading from any object with attrs / shader / shininess_log2 / light_dir / half_dir / ambient /
+    diffuse / specular / texture fields (scenes.Shading).  Returns (struct, keep-alive tuple)."""
+    a = np.ascontiguousarray(shading.attrs, dtype=np.float32)
+    t = None if shading.texture is None else np.ascontiguousarray(shading.texture, dtype=np.uint8)
+    m = Material(int(shading.shader), int(shading.shininess_log2),
+                 (ctypes.c_float * 4)(*[float(x) for x in shading.light_dir], 0.0),
+                 (ctypes.c_float * 4)(*[float(x) for x in shading.half_dir], 0.0),
+                 float(shading.ambient), float(shading.diffuse), float(shading.specular), 0.0)
+    sc = ShadingC(a.ctypes.data, m, None if t is None else t.ctypes.data,
+                  0 if t is None else t.shape[1], 0 if t is None else t.shape[0])
+    return sc, (a, t)
+
+
 def build(force: bool = False) -> str:
     src = os.path.join(_HERE, "swr_oracle.c")
     if force or not os.path.exists(_LIB_PATH) or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src):
@@ -52,6 +78,13 @@ def lib():
                                              ctypes.c_int64, ctypes.POINTER(Stats)]
         L.swro_render_metal.restype = ctypes.c_int
         L.swro_render_metal.argtypes = L.swro_render.argtypes
+        L.swro_render_shaded.restype = ctypes.c_int
+        L.swro_render_shaded.argtypes = L.swro_render.argtypes + [ctypes.POINTER(ShadingC)]
+        L.swro_render_metal_shaded.restype = ctypes.c_int
+        L.swro_render_metal_shaded.argtypes = L.swro_render_shaded.argtypes
+        L.swro_fragment.restype = None
+        L.swro_fragment.argtypes = [ctypes.POINTER(ShadingC), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                    ctypes.c_void_p]
         L.swro_interpolate.restype = ctypes.c_int64
         L.swro_interpolate.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int64]
         L.swro_quantise.restype = ctypes.c_uint8
@@ -62,8 +95,10 @@ def lib():
 
 def render(vertices: np.ndarray, indices: np.ndarray, transform: np.ndarray, width: int, height: int,
            flags: int = 0, row_begin: int = 0, row_end: int | None = None,
-           color: np.ndarray | None = None, depth: np.ndarray | None = None, primitive_type: int = 0):
-    """Returns (color uint8[H,W,4] BGRA or None, depth float32[H,W], Stats, rc)."""
+           color: np.ndarray | None = None, depth: np.ndarray | None = None, primitive_type: int = 0,
+           shading=None):
+    """Returns (color uint8[H,W,4] BGRA or None, depth float32[H,W], Stats, rc).
+    shading: the extended fragment stage (scenes.Shading; triangles only)."""
     L = lib()
     v = np.ascontiguousarray(vertices, dtype=np.float32)
     i = np.ascontiguousarray(indices, dtype=np.int64)
@@ -75,6 +110,14 @@ def render(vertices: np.ndarray, indices: np.ndarray, transform: np.ndarray, wid
     if depth is None:
         depth = np.full((height, width), -123.0, dtype=np.float32)
     st = Stats()
+    if shading is not None:
+        assert primitive_type == 0
+        sc, keep = _shading_c(shading)
+        rc = L.swro_render_shaded(color.ctypes.data if color is not None else None, depth.ctypes.data,
+                                  width, height, v.ctypes.data, v.shape[0] if v.ndim == 2 else v.size // 8,
+                                  i.ctypes.data, i.size, m.ctypes.data, flags, row_begin, row_end,
+                                  ctypes.byref(st), ctypes.byref(sc))
+        return color, depth, st, rc
     rc = L.swro_render_primitives(color.ctypes.data if color is not None else None, depth.ctypes.data,
                                   width, height, v.ctypes.data, v.shape[0] if v.ndim == 2 else v.size // 8,
                                   i.ctypes.data, i.size, m.ctypes.data, flags, primitive_type, row_begin, row_end,
@@ -83,7 +126,7 @@ def render(vertices: np.ndarray, indices: np.ndarray, transform: np.ndarray, wid
 
 
 def render_metal(vertices, indices, transform, width: int, height: int, flags: int = 0,
-                 row_begin: int = 0, row_end: int | None = None, color=None, depth=None):
+                 row_begin: int = 0, row_end: int | None = None, color=None, depth=None, shading=None):
     """The Metal path's rules (Shaders.metal / GpuRenderer.swift) in IEEE arithmetic."""
     L = lib()
     v = np.ascontiguousarray(vertices, dtype=np.float32)
@@ -96,6 +139,13 @@ def render_metal(vertices, indices, transform, width: int, height: int, flags: i
     if depth is None:
         depth = np.full((height, width), -123.0, dtype=np.float32)
     st = Stats()
+    if shading is not None:
+        sc, keep = _shading_c(shading)
+        rc = L.swro_render_metal_shaded(color.ctypes.data if color is not None else None, depth.ctypes.data,
+                                        width, height, v.ctypes.data, v.shape[0] if v.ndim == 2 else v.size // 8,
+                                        i.ctypes.data, i.size, m.ctypes.data, flags, row_begin, row_end,
+                                        ctypes.byref(st), ctypes.byref(sc))
+        return color, depth, st, rc
     rc = L.swro_render_metal(color.ctypes.data if color is not None else None, depth.ctypes.data, width, height,
                              v.ctypes.data, v.shape[0] if v.ndim == 2 else v.size // 8, i.ctypes.data, i.size,
                              m.ctypes.data, flags, row_begin, row_end, ctypes.byref(st))
@@ -122,6 +172,17 @@ def render_threads(scene, threads: int, extra_flags: int = 0):
     with ThreadPoolExecutor(max_workers=threads) as ex:
         rcs = list(ex.map(job, range(threads)))
     return color, depth, rcs
+
+
+def fragment(shading, color, normal, uv) -> np.ndarray:
+    """swro_fragment on one fragment: returns float32[4] r,g,b,a."""
+    sc, keep = _shading_c(shading)
+    c = np.ascontiguousarray(color, dtype=np.float32)
+    n = np.ascontiguousarray(normal, dtype=np.float32)
+    t = np.ascontiguousarray(uv, dtype=np.float32)
+    out = np.zeros(4, dtype=np.float32)
+    lib().swro_fragment(ctypes.byref(sc), c.ctypes.data, n.ctypes.data, t.ctypes.data, out.ctypes.data)
+    return out
 
 
 def interpolate(points, t: int) -> int:

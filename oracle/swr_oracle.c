@@ -22,6 +22,7 @@ typedef struct {
     /* Vertex after apply(transform:) and convertedToScreen (floats), in index order a,b,c */
     float sx[3], sy[3], sz[3];
     float col[3][3];
+    float nrm[3][3], uv[3][2];   /* extended varyings (swro_shading), index order a,b,c */
     /* simd_long2(a.xyz.xy) etc. (:251): truncated integer vertices in index order */
     int64_t ix[3], iy[3];
     /* sorted-by-float-y list, truncated (:271) */
@@ -36,6 +37,63 @@ typedef struct {
     uint32_t flags;
     swro_stats st;
 } frame_t;
+
+/* extended fragment stage of the current swro_render*_shaded call on this thread (NULL: the reference's) */
+static __thread const swro_shading* tls_shading = NULL;
+
+/* one texel channel triple as floats in [0,1]: Pixel is b,g,r,a (Renderer.swift:44-49) */
+static void texel(const swro_shading* sh, int64_t x, int64_t y, float rgb[3]) {
+    const int64_t tw = sh->tex_w, th = sh->tex_h;
+    x = ((x % tw) + tw) % tw;                       /* repeat */
+    y = ((y % th) + th) % th;
+    const uint8_t* p = sh->texture + (size_t)(y * tw + x) * 4;
+    rgb[0] = (float)p[2] / 255.0f;
+    rgb[1] = (float)p[1] / 255.0f;
+    rgb[2] = (float)p[0] / 255.0f;
+}
+
+/* see swr_oracle.h */
+void swro_fragment(const swro_shading* sh, const float color[3], const float normal[3], const float uv[2],
+                   float out[4]) {
+    const swro_material* m = &sh->material;
+    if (m->shader == 0) {                           /* Shaders.metal:116-121 */
+        out[0] = color[0]; out[1] = color[1]; out[2] = color[2]; out[3] = 1.0f;
+        return;
+    }
+    float len2 = normal[0] * normal[0] + normal[1] * normal[1] + normal[2] * normal[2];
+    float N[3] = {0.0f, 0.0f, 0.0f};
+    if (len2 > 0.0f) {
+        float len = sqrtf(len2);
+        N[0] = normal[0] / len; N[1] = normal[1] / len; N[2] = normal[2] / len;
+    }
+    float ndl = N[0] * m->light_dir[0] + N[1] * m->light_dir[1] + N[2] * m->light_dir[2];
+    ndl = fmaxf(ndl, 0.0f);
+    float ndh = N[0] * m->half_dir[0] + N[1] * m->half_dir[1] + N[2] * m->half_dir[2];
+    ndh = fmaxf(ndh, 0.0f);
+    float s = ndh;
+    for (int i = 0; i < m->shininess_log2; i++) s = s * s;
+    float base[3] = {color[0], color[1], color[2]};
+    if (m->shader == 2) {
+        const float fu = uv[0] - floorf(uv[0]), fv = uv[1] - floorf(uv[1]);
+        const float x = fu * (float)sh->tex_w - 0.5f, y = fv * (float)sh->tex_h - 0.5f;
+        const float x0f = floorf(x), y0f = floorf(y);
+        const float ax = x - x0f, ay = y - y0f;
+        const int64_t x0 = (int64_t)x0f, y0 = (int64_t)y0f;
+        float t00[3], t10[3], t01[3], t11[3];
+        texel(sh, x0, y0, t00); texel(sh, x0 + 1, y0, t10);
+        texel(sh, x0, y0 + 1, t01); texel(sh, x0 + 1, y0 + 1, t11);
+        for (int k = 0; k < 3; k++) {
+            float top = t00[k] + (t10[k] - t00[k]) * ax;
+            float bot = t01[k] + (t11[k] - t01[k]) * ax;
+            float t = top + (bot - top) * ay;
+            base[k] = base[k] * t;
+        }
+    }
+    const float lit = m->ambient + m->diffuse * ndl;
+    const float spec = m->specular * s;
+    for (int k = 0; k < 3; k++) out[k] = base[k] * lit + spec;
+    out[3] = 1.0f;
+}
 
 /* Pixel.floats (:117-124): UInt8(simd_clamp(v, 0, 1) * 255), truncation toward zero.
  * simd_clamp = min(max(v,lo),hi) with fmax/fmin NaN handling (NaN -> lo). */
@@ -108,11 +166,18 @@ static void set_pixel(frame_t* f, const tri_t* t, int64_t x, int64_t y,
     float c[3];
     for (int k = 0; k < 3; k++)                                   /* :266 */
         c[k] = t->col[0][k] * w0 + t->col[1][k] * w1 + t->col[2][k] * w2;
+    float o[4] = {c[0], c[1], c[2], 1.0f};                        /* fragment_shader: float4(color, 1) */
+    if (tls_shading) {
+        float n[3], uv[2];
+        for (int k = 0; k < 3; k++) n[k] = t->nrm[0][k] * w0 + t->nrm[1][k] * w1 + t->nrm[2][k] * w2;
+        for (int k = 0; k < 2; k++) uv[k] = t->uv[0][k] * w0 + t->uv[1][k] * w1 + t->uv[2][k] * w2;
+        swro_fragment(tls_shading, c, n, uv, o);
+    }
     uint8_t* p = f->color + at * 4;                               /* Pixel(float3:) :126-128 */
-    p[0] = swro_quantise(c[2]);  /* b */
-    p[1] = swro_quantise(c[1]);  /* g */
-    p[2] = swro_quantise(c[0]);  /* r */
-    p[3] = swro_quantise(1.0f);  /* a */
+    p[0] = swro_quantise(o[2]);  /* b */
+    p[1] = swro_quantise(o[1]);  /* g */
+    p[2] = swro_quantise(o[0]);  /* r */
+    p[3] = swro_quantise(o[3]);  /* a */
 }
 
 /* draw(triangle:colorBuffer:depthBuffer:) (:238-287); input already transformed. */
@@ -209,6 +274,11 @@ int swro_render(uint8_t* color, float* depth, int64_t W, int64_t H,
             t.sy[k] = w * fh;
             t.sz[k] = nz;
             t.col[k][0] = v->color[0]; t.col[k][1] = v->color[1]; t.col[k][2] = v->color[2];
+            if (tls_shading) {
+                const swro_vertex_attr* av = &tls_shading->attrs[indices[3 * p + k]];
+                t.nrm[k][0] = av->normal[0]; t.nrm[k][1] = av->normal[1]; t.nrm[k][2] = av->normal[2];
+                t.uv[k][0] = av->uv[0]; t.uv[k][1] = av->uv[1];
+            }
             if (!(fabsf(t.sx[k]) < COORD_LIMIT) || !(fabsf(t.sy[k]) < COORD_LIMIT)) { ok = 0; }
             else { t.ix[k] = (int64_t)t.sx[k]; t.iy[k] = (int64_t)t.sy[k]; }   /* :251 truncation */
         }
@@ -312,7 +382,7 @@ int swro_render_metal(uint8_t* color, float* depth, int64_t W, int64_t H,
 
     const float fw = (float)W, fh = (float)H;
     for (int64_t p = 0; p < index_count / 3; p++) {               /* serial dispatches, GpuRenderer.swift:117 */
-        float px[3], py[3], pz[3], col[3][3];
+        float px[3], py[3], pz[3], col[3][3], nrm[3][3] = {{0}}, tuv[3][2] = {{0}};
         int ok = 1;
         for (int k = 0; k < 3; k++) {
             const swro_vertex* v = &vertices[indices[3 * p + k]];
@@ -331,6 +401,11 @@ int swro_render_metal(uint8_t* color, float* depth, int64_t W, int64_t H,
             py[k] = roundf(w * fh);
             pz[k] = nz;
             for (int c = 0; c < 3; c++) col[k][c] = v->color[c];
+            if (tls_shading) {
+                const swro_vertex_attr* av = &tls_shading->attrs[indices[3 * p + k]];
+                for (int c = 0; c < 3; c++) nrm[k][c] = av->normal[c];
+                tuv[k][0] = av->uv[0]; tuv[k][1] = av->uv[1];
+            }
             /* uint2(pos.xy) (:102-104): undefined for negative / non-finite -> skip (documented) */
             if (!(px[k] >= 0.0f && px[k] < COORD_LIMIT) || !(py[k] >= 0.0f && py[k] < COORD_LIMIT)) ok = 0;
         }
@@ -367,12 +442,55 @@ int swro_render_metal(uint8_t* color, float* depth, int64_t W, int64_t H,
                     float c[3];
                     for (int ch = 0; ch < 3; ch++)                                           /* :162 */
                         c[ch] = w0 * col[0][ch] + w1 * col[1][ch] + w2 * col[2][ch];
+                    float o[4] = {c[0], c[1], c[2], 1.0f};                                   /* fragment_shader :116-121 */
+                    if (tls_shading) {
+                        float n[3], uv[2];
+                        for (int ch = 0; ch < 3; ch++) n[ch] = w0 * nrm[0][ch] + w1 * nrm[1][ch] + w2 * nrm[2][ch];
+                        for (int ch = 0; ch < 2; ch++) uv[ch] = w0 * tuv[0][ch] + w1 * tuv[1][ch] + w2 * tuv[2][ch];
+                        swro_fragment(tls_shading, c, n, uv, o);
+                    }
                     uint8_t* q = color + at * 4;                                             /* :163 bgra8Unorm */
-                    q[0] = unorm8(c[2]); q[1] = unorm8(c[1]); q[2] = unorm8(c[0]); q[3] = unorm8(1.0f);
+                    q[0] = unorm8(o[2]); q[1] = unorm8(o[1]); q[2] = unorm8(o[0]); q[3] = unorm8(o[3]);
                 }
                 depth[at] = z;                                                               /* :164 */
             }
     }
     if (stats) *stats = st;
     return 0;
+}
+
+/* ---- extended fragment stage: the same two renderers with swro_fragment at the colour store ---- */
+static int shading_ok(const swro_shading* sh, int64_t vertex_count) {
+    if (!sh || sh->material.shader == 0) return 1;
+    if (sh->material.shader != 1 && sh->material.shader != 2) return 0;
+    if (vertex_count > 0 && !sh->attrs) return 0;
+    if (sh->material.shininess_log2 < 0 || sh->material.shininess_log2 > 16) return 0;
+    if (sh->material.shader == 2 && (!sh->texture || sh->tex_w <= 0 || sh->tex_h <= 0)) return 0;
+    return 1;
+}
+
+int swro_render_shaded(uint8_t* color, float* depth, int64_t W, int64_t H,
+                       const swro_vertex* vertices, int64_t vertex_count,
+                       const int64_t* indices, int64_t index_count,
+                       const float M[16], uint32_t flags,
+                       int64_t row_begin, int64_t row_end, swro_stats* stats, const swro_shading* sh) {
+    if (!shading_ok(sh, vertex_count)) return -1;
+    tls_shading = (sh && sh->material.shader != 0) ? sh : NULL;
+    int rc = swro_render(color, depth, W, H, vertices, vertex_count, indices, index_count, M, flags,
+                         row_begin, row_end, stats);
+    tls_shading = NULL;
+    return rc;
+}
+
+int swro_render_metal_shaded(uint8_t* color, float* depth, int64_t W, int64_t H,
+                             const swro_vertex* vertices, int64_t vertex_count,
+                             const int64_t* indices, int64_t index_count,
+                             const float M[16], uint32_t flags,
+                             int64_t row_begin, int64_t row_end, swro_stats* stats, const swro_shading* sh) {
+    if (!shading_ok(sh, vertex_count)) return -1;
+    tls_shading = (sh && sh->material.shader != 0) ? sh : NULL;
+    int rc = swro_render_metal(color, depth, W, H, vertices, vertex_count, indices, index_count, M, flags,
+                               row_begin, row_end, stats);
+    tls_shading = NULL;
+    return rc;
 }

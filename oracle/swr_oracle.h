@@ -86,6 +86,50 @@ int swro_render_metal(uint8_t* color, float* depth, int64_t W, int64_t H,
                       const float transform[16], uint32_t flags,
                       int64_t row_begin, int64_t row_end, swro_stats* stats);
 
+/* ---- fragment-stage extensions (include/swr.h swr_vertex_attr / swr_material) ----
+ * NOT IN THE REFERENCE: its fragment stage is float4(color, 1) (Shaders.metal:116-121).  This is the
+ * normative definition of the extended stage; the HIP kernels are checked against it bit for bit.
+ * Varyings normal / uv are interpolated with the same weights and expression shape as colour
+ * (a*w0 + b*w1 + c*w2, Renderer.swift:266).  swro_fragment, one IEEE binary32 op per operator:
+ *   len2 = nx*nx + ny*ny + nz*nz;  N = len2 > 0 ? n / sqrtf(len2) : 0
+ *   ndl = fmaxf(N.x*L.x + N.y*L.y + N.z*L.z, 0);  ndh = fmaxf(N.H, 0);  s = ndh squared shininess_log2 times
+ *   base = color                      (shader 1)
+ *        = color * bilinear(tex, uv)  (shader 2; repeat addressing, texel centres at +0.5, channel/255)
+ *   rgb = base * (ambient + diffuse*ndl) + specular*s;  a = 1 */
+typedef struct swro_vertex_attr {
+    float normal[4];
+    float uv[4];
+} swro_vertex_attr;
+typedef struct swro_material {
+    int32_t shader;
+    int32_t shininess_log2;
+    float light_dir[4];
+    float half_dir[4];
+    float ambient, diffuse, specular, reserved;
+} swro_material;
+typedef struct swro_shading {
+    const swro_vertex_attr* attrs;   /* vertex_count entries */
+    swro_material material;
+    const uint8_t* texture;          /* tex_w*tex_h*4 bytes b,g,r,a */
+    int32_t tex_w, tex_h;
+} swro_shading;
+
+void swro_fragment(const swro_shading* sh, const float color[3], const float normal[3], const float uv[2],
+                   float out_rgba[4]);
+
+/* swro_render / swro_render_metal with the extended fragment stage (sh == NULL or shader 0: identical to
+ * the plain entry points). */
+int swro_render_shaded(uint8_t* color, float* depth, int64_t W, int64_t H,
+                       const swro_vertex* vertices, int64_t vertex_count,
+                       const int64_t* indices, int64_t index_count,
+                       const float transform[16], uint32_t flags,
+                       int64_t row_begin, int64_t row_end, swro_stats* stats, const swro_shading* sh);
+int swro_render_metal_shaded(uint8_t* color, float* depth, int64_t W, int64_t H,
+                             const swro_vertex* vertices, int64_t vertex_count,
+                             const int64_t* indices, int64_t index_count,
+                             const float transform[16], uint32_t flags,
+                             int64_t row_begin, int64_t row_end, swro_stats* stats, const swro_shading* sh);
+
 /* Renderer.interpolate(values:t:) (Renderer.swift:467-494), exposed for unit tests.
  * pts = n (x,y) pairs, n in {2,3}. */
 int64_t swro_interpolate(const int64_t* pts_xy, int n, int64_t t);

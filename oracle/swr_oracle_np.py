@@ -44,8 +44,74 @@ def quantise(v: np.ndarray) -> np.ndarray:
     return (c * F(255.0)).astype(np.uint8)
 
 
+def fragment(sh, c, n, uv):
+    """The extended fragment stage (swr_oracle.h, swro_fragment) on arrays of fragments: c [k,3] interpolated
+    colour, n [k,3] interpolated normal, uv [k,2]; returns r,g,b,a float32 [k,4].  Written from the definition
+    in swr_oracle.h, one float32 ufunc per operator."""
+    c = np.asarray(c, dtype=F); n = np.asarray(n, dtype=F); uv = np.asarray(uv, dtype=F)
+    k = c.shape[0]
+    out = np.empty((k, 4), dtype=F)
+    out[:, 3] = F(1.0)
+    if sh.shader == 0:
+        out[:, 0:3] = c
+        return out
+    with np.errstate(all="ignore"):
+        len2 = n[:, 0] * n[:, 0] + n[:, 1] * n[:, 1] + n[:, 2] * n[:, 2]
+        ln = np.sqrt(len2)
+        pos = len2 > 0
+        N = np.zeros((k, 3), dtype=F)
+        for a in range(3):
+            N[pos, a] = n[pos, a] / ln[pos]
+        L = [F(x) for x in sh.light_dir]
+        Hh = [F(x) for x in sh.half_dir]
+        ndl = np.fmax(N[:, 0] * L[0] + N[:, 1] * L[1] + N[:, 2] * L[2], F(0))
+        ndh = np.fmax(N[:, 0] * Hh[0] + N[:, 1] * Hh[1] + N[:, 2] * Hh[2], F(0))
+        s = ndh
+        for _ in range(int(sh.shininess_log2)):
+            s = s * s
+        base = c.copy()
+        if sh.shader == 2:
+            tex = np.asarray(sh.texture, dtype=np.uint8)
+            th, tw = tex.shape[0], tex.shape[1]
+            fu = uv[:, 0] - np.floor(uv[:, 0])
+            fv = uv[:, 1] - np.floor(uv[:, 1])
+            x = fu * F(tw) - F(0.5)
+            y = fv * F(th) - F(0.5)
+            x0f, y0f = np.floor(x), np.floor(y)
+            ax, ay = x - x0f, y - y0f
+            x0, y0 = x0f.astype(np.int64), y0f.astype(np.int64)
+
+            def texel(xi, yi):
+                t = tex[np.mod(yi, th), np.mod(xi, tw)]                  # b,g,r,a
+                return t[:, [2, 1, 0]].astype(F) / F(255.0)              # r,g,b
+
+            t00, t10, t01, t11 = texel(x0, y0), texel(x0 + 1, y0), texel(x0, y0 + 1), texel(x0 + 1, y0 + 1)
+            top = t00 + (t10 - t00) * ax[:, None]
+            bot = t01 + (t11 - t01) * ax[:, None]
+            base = base * (top + (bot - top) * ay[:, None])
+        lit = F(sh.ambient) + F(sh.diffuse) * ndl
+        spec = F(sh.specular) * s
+        out[:, 0:3] = base * lit[:, None] + spec[:, None]
+    return out
+
+
+def _shaded(shading, sel_attr, w0, w1, w2, rgb, metal):
+    """interpolate normal / uv like colour and run the fragment stage; rgb: list of 3 arrays."""
+    na, nb, nc = sel_attr
+    if metal:
+        n = [w0 * na[ch] + w1 * nb[ch] + w2 * nc[ch] for ch in range(3)]
+        uv = [w0 * na[4 + ch] + w1 * nb[4 + ch] + w2 * nc[4 + ch] for ch in range(2)]
+    else:
+        n = [na[ch] * w0 + nb[ch] * w1 + nc[ch] * w2 for ch in range(3)]
+        uv = [na[4 + ch] * w0 + nb[4 + ch] * w1 + nc[4 + ch] * w2 for ch in range(2)]
+    shp = w0.shape
+    o = fragment(shading, np.stack([r.reshape(-1) for r in rgb], -1), np.stack([q.reshape(-1) for q in n], -1),
+                 np.stack([q.reshape(-1) for q in uv], -1))
+    return [o[:, 0].reshape(shp), o[:, 1].reshape(shp), o[:, 2].reshape(shp)], o[:, 3].reshape(shp)
+
+
 def render(vertices, indices, transform, width, height, depth_test=False, no_color=False,
-           inv_rcp=False):
+           inv_rcp=False, shading=None):
     W, H = int(width), int(height)
     color = np.zeros((H, W, 4), dtype=np.uint8)            # clear :205
     depth = np.full((H, W), np.inf, dtype=F)               # clear :206
@@ -117,14 +183,17 @@ def render(vertices, indices, transform, width, height, depth_test=False, no_col
                     continue
                 ca, cb, cc = sv[0][3], sv[1][3], sv[2][3]
                 rgb = [ca[ch] * w0 + cb[ch] * w1 + cc[ch] * w2 for ch in range(3)]
-                px = np.stack([quantise(rgb[2]), quantise(rgb[1]), quantise(rgb[0]),
-                               np.full(xs.shape, 255, dtype=np.uint8)], axis=-1)
+                alpha = np.full(xs.shape, F(1.0), dtype=F)
+                if shading is not None and shading.shader != 0:
+                    A = np.asarray(shading.attrs, dtype=F).reshape(-1, 8)
+                    rgb, alpha = _shaded(shading, [A[idx[3 * p + k]] for k in range(3)], w0, w1, w2, rgb, False)
+                px = np.stack([quantise(rgb[2]), quantise(rgb[1]), quantise(rgb[0]), quantise(alpha)], axis=-1)
                 row = color[y, x0:x1 + 1]
                 row[sel] = px[sel]
     return color, depth, skipped
 
 
-def render_metal(vertices, indices, transform, width, height, no_color=False):
+def render_metal(vertices, indices, transform, width, height, no_color=False, shading=None):
     """Independent NumPy restatement of the Metal path's rules (renderer/Shaders.metal:57-167,
     renderer/GpuRenderer.swift:109-139) in IEEE float32 — see swr_oracle.h for the documented choices.
     Vectorised over the ROI of each primitive."""
@@ -178,8 +247,12 @@ def render_metal(vertices, indices, transform, width, height, no_color=False):
             sub[win] = z[win]
             if not no_color:
                 rgb = [w0 * C[0][ch] + w1 * C[1][ch] + w2 * C[2][ch] for ch in range(3)]
+                alpha = np.full(z.shape, F(1.0), dtype=F)
+                if shading is not None and shading.shader != 0:
+                    A = np.asarray(shading.attrs, dtype=F).reshape(-1, 8)
+                    rgb, alpha = _shaded(shading, [A[idx[3 * p + k]] for k in range(3)], w0, w1, w2, rgb, True)
                 un = lambda a: np.rint(np.fmin(np.fmax(a, F(0)), F(1)) * F(255)).astype(np.uint8)
-                px4 = np.stack([un(rgb[2]), un(rgb[1]), un(rgb[0]), np.full(z.shape, 255, np.uint8)], axis=-1)
+                px4 = np.stack([un(rgb[2]), un(rgb[1]), un(rgb[0]), un(alpha)], axis=-1)
                 csub = color[y0:y1 + 1, x0:x1 + 1]
                 csub[win] = px4[win]
     return color, depth

@@ -19,7 +19,7 @@ ABI_SYMBOLS = [
     "swr_abi_version", "swr_version", "swr_context_create", "swr_context_destroy", "swr_last_error",
     "swr_render", "swr_scene_upload", "swr_target_set", "swr_draw", "swr_draw_primitives", "swr_sync", "swr_read_color",
     "swr_read_depth", "swr_timing_enable", "swr_get_timings", "swr_timing_totals", "swr_timing_reset", "swr_pipeline_enable", "swr_tile_rows", "swr_tile_cols",
-    "swr_band_rows",
+    "swr_band_rows", "swr_scene_attributes", "swr_material_set", "swr_texture_upload",
 ]
 
 
@@ -39,7 +39,24 @@ class RenderPass(ctypes.Structure):
         ("indices", ctypes.c_void_p), ("index_count", ctypes.c_int64),
         ("primitive_type", ctypes.c_int32), ("flags", ctypes.c_uint32),
         ("transform", ctypes.c_float * 16),
+        ("attributes", ctypes.c_void_p), ("material", ctypes.c_void_p), ("texture", ctypes.c_void_p),
+        ("tex_width", ctypes.c_int32), ("tex_height", ctypes.c_int32),
     ]
+
+
+class Material(ctypes.Structure):
+    """swr_material (include/swr.h): the extended fragment stage."""
+    _fields_ = [("shader", ctypes.c_int32), ("shininess_log2", ctypes.c_int32),
+                ("light_dir", ctypes.c_float * 4), ("half_dir", ctypes.c_float * 4),
+                ("ambient", ctypes.c_float), ("diffuse", ctypes.c_float), ("specular", ctypes.c_float),
+                ("reserved", ctypes.c_float)]
+
+    @classmethod
+    def from_shading(cls, sh):
+        return cls(int(sh.shader), int(sh.shininess_log2),
+                   (ctypes.c_float * 4)(*[float(x) for x in sh.light_dir], 0.0),
+                   (ctypes.c_float * 4)(*[float(x) for x in sh.half_dir], 0.0),
+                   float(sh.ambient), float(sh.diffuse), float(sh.specular), 0.0)
 
 
 class Config(ctypes.Structure):
@@ -105,6 +122,11 @@ def load_library():
     L.swr_pipeline_enable.argtypes = [vp, ctypes.c_int]
     L.swr_pipeline_enable.restype = ctypes.c_int
     L.swr_band_rows.argtypes = [i64, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    L.swr_scene_attributes.argtypes = [vp, vp, i64]
+    L.swr_material_set.argtypes = [vp, ctypes.POINTER(Material)]
+    L.swr_texture_upload.argtypes = [vp, vp, i32, i32]
+    for name in ("swr_scene_attributes", "swr_material_set", "swr_texture_upload"):
+        getattr(L, name).restype = ctypes.c_int
     for name in ("swr_context_create", "swr_render", "swr_scene_upload", "swr_target_set", "swr_draw",
                  "swr_sync", "swr_read_color", "swr_read_depth", "swr_timing_enable", "swr_get_timings", "swr_timing_totals", "swr_timing_reset",
                  "swr_band_rows", "swr_tile_rows", "swr_tile_cols"):
@@ -167,6 +189,28 @@ class Context:
         i = np.ascontiguousarray(indices, dtype=np.int64).reshape(-1)
         self._check(self._L.swr_scene_upload(self._h, v.ctypes.data, v.shape[0], i.ctypes.data, i.size))
 
+    def scene_attributes(self, attrs: np.ndarray):
+        a = np.ascontiguousarray(attrs, dtype=np.float32).reshape(-1, 8)
+        self._check(self._L.swr_scene_attributes(self._h, a.ctypes.data, a.shape[0]))
+
+    def material_set(self, material: "Material | None"):
+        self._check(self._L.swr_material_set(self._h, ctypes.byref(material) if material is not None else None))
+
+    def texture_upload(self, texture: np.ndarray):
+        t = np.ascontiguousarray(texture, dtype=np.uint8)
+        assert t.ndim == 3 and t.shape[2] == 4
+        self._check(self._L.swr_texture_upload(self._h, t.ctypes.data, t.shape[1], t.shape[0]))
+
+    def shading_set(self, shading):
+        """attributes + material + texture of a scenes.Shading (None: back to the reference's stage)."""
+        if shading is None:
+            self.material_set(None)
+            return
+        self.scene_attributes(shading.attrs)
+        if shading.texture is not None:
+            self.texture_upload(shading.texture)
+        self.material_set(Material.from_shading(shading))
+
     def target_set(self, width: int, height: int, row_begin: int = 0, row_end: int | None = None):
         if row_end is None:
             row_end = height
@@ -219,7 +263,7 @@ class Context:
 
     # -- one-shot path: Renderer.render(renderPass:) / GpuRenderer.render(renderPass:) -----
     def render(self, vertices, indices, transform, width, height, flags=0, primitive_type=0,
-               color=None, depth=None):
+               color=None, depth=None, shading=None):
         v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 8)
         i = np.ascontiguousarray(indices, dtype=np.int64).reshape(-1)
         m = np.ascontiguousarray(transform, dtype=np.float32).reshape(16)
@@ -237,6 +281,14 @@ class Context:
         rp.indices, rp.index_count = i.ctypes.data, i.size
         rp.primitive_type, rp.flags = primitive_type, flags
         rp.transform = (ctypes.c_float * 16)(*m.tolist())
+        if shading is not None:
+            a = np.ascontiguousarray(shading.attrs, dtype=np.float32).reshape(-1, 8)
+            mat = Material.from_shading(shading)
+            rp.attributes = a.ctypes.data
+            rp.material = ctypes.addressof(mat)
+            if shading.texture is not None:
+                t = np.ascontiguousarray(shading.texture, dtype=np.uint8)
+                rp.texture, rp.tex_width, rp.tex_height = t.ctypes.data, t.shape[1], t.shape[0]
         self._check(self._L.swr_render(self._h, ctypes.byref(rp)))
         return color, depth
 
@@ -245,4 +297,4 @@ def render(scene, extra_flags: int = 0, device: int = -1):
     """Convenience: one-shot render of a scenes.Scene; returns (color, depth)."""
     with Context(device) as ctx:
         return ctx.render(scene.vertices, scene.indices, scene.transform, scene.width, scene.height,
-                          scene.flags | extra_flags)
+                          scene.flags | extra_flags, shading=scene.shading)

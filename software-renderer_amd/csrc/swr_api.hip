@@ -26,6 +26,9 @@ struct DevBuf {
 };
 }  // namespace
 
+static_assert(sizeof(swr_render_pass) == 184 && sizeof(swr_material) == 56 && sizeof(swr_vertex_attr) == 32 &&
+              sizeof(swr_vertex) == 32, "include/swr.h layouts (mirrored by the ctypes / Swift bindings)");
+
 struct swr_context {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -35,6 +38,11 @@ struct swr_context {
     DevBuf vertices, indices, xyz, rgb, idx32, tri_rgb;
     int64_t nv = 0, ni = 0;
     bool has_scene = false;
+    // extended fragment stage (swr_scene_attributes / swr_material_set / swr_texture_upload)
+    DevBuf attrs, tri_nrm, texture, texture_bytes;   // texture: float4 texels; texture_bytes: upload staging
+    bool has_attrs = false;
+    swr_material material{};            // shader 0 = the reference's passthrough stage
+    int32_t tex_w = 0, tex_h = 0;
 
     // target band (RenderPass.colorBuffer / .depthBuffer)
     Target tg{};
@@ -138,6 +146,10 @@ DeviceFrame make_frame(swr_context* c, int si, const float m[16], uint32_t flags
     f.rgb = (const float4*)c->rgb.p;
     f.idx32 = (const uint32_t*)c->idx32.p;
     f.tri_rgb = (const float4*)c->tri_rgb.p;
+    f.tri_nrm = (const float4*)c->tri_nrm.p;
+    f.material = c->material;
+    f.texels = (const float4*)c->texture.p;
+    f.tex_w = c->tex_w; f.tex_h = c->tex_h;
     f.vertex_count = c->nv;
     f.ntri = c->ni / 3;
     f.geo = (GeomRec*)sl.geo.p;
@@ -325,7 +337,7 @@ void swr_context_destroy(swr_context* c) {
     hipSetDevice(c->device);
     if (c->bin_stream) hipStreamSynchronize(c->bin_stream);
     if (c->stream) hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->xyz, &c->rgb, &c->idx32, &c->tri_rgb, &c->color, &c->depth};
+    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->xyz, &c->rgb, &c->idx32, &c->tri_rgb, &c->attrs, &c->tri_nrm, &c->texture, &c->texture_bytes, &c->color, &c->depth};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& sl : c->slot) {
         DevBuf* sb[] = {&sl.geo, &sl.geo_full, &sl.ranges, &sl.bins, &sl.bin_matrix, &sl.tilebuf};
@@ -352,6 +364,7 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     HIP_TRY(c, hipSetDevice(c->device));
     { int rcs = sync_streams(c); if (rcs) return rcs; }
     c->has_scene = false;
+    c->has_attrs = false;
     c->draw_pending = false;
     int rc;
     if ((rc = ensure(c, c->vertices, (size_t)vertex_count * sizeof(swr_vertex)))) return rc;
@@ -386,6 +399,57 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     c->has_scene = true;
     const uint64_t want = (uint64_t)(index_count / 3) * 2 + 65536;
     return ensure_capacity(c, (uint32_t)std::min<uint64_t>(want, 0xFFFFFFF0ull));
+}
+
+int swr_scene_attributes(swr_context* c, const swr_vertex_attr* attributes, int64_t vertex_count) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    if (!c->has_scene) return fail(c, SWR_ERR_NO_SCENE, "swr_scene_attributes needs swr_scene_upload first");
+    if (vertex_count != c->nv || (vertex_count > 0 && !attributes))
+        return fail(c, SWR_ERR_BAD_ARG, "swr_scene_attributes: %lld attributes for %lld vertices",
+                    (long long)vertex_count, (long long)c->nv);
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rcs = sync_streams(c); if (rcs) return rcs; }
+    int rc;
+    if ((rc = ensure(c, c->attrs, (size_t)vertex_count * sizeof(swr_vertex_attr)))) return rc;
+    if ((rc = ensure(c, c->tri_nrm, (size_t)c->ni * 16))) return rc;
+    if (vertex_count)
+        HIP_TRY(c, hipMemcpyAsync(c->attrs.p, attributes, (size_t)vertex_count * sizeof(swr_vertex_attr),
+                                  hipMemcpyHostToDevice, c->stream));
+    launch_split_attrs((const swr_vertex_attr*)c->attrs.p, vertex_count, (const uint32_t*)c->idx32.p, c->ni,
+                       (float4*)c->tri_nrm.p, (float4*)c->tri_rgb.p, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->has_attrs = true;
+    return SWR_OK;
+}
+
+int swr_material_set(swr_context* c, const swr_material* m) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    if (!m) { c->material = swr_material{}; return SWR_OK; }
+    if (m->shader != SWR_SHADER_PASSTHROUGH && m->shader != SWR_SHADER_PHONG && m->shader != SWR_SHADER_TEXTURED_PHONG)
+        return fail(c, SWR_ERR_UNSUPPORTED, "unknown shader %d", m->shader);
+    if (m->shininess_log2 < 0 || m->shininess_log2 > 16)
+        return fail(c, SWR_ERR_BAD_ARG, "shininess_log2 %d outside [0,16]", m->shininess_log2);
+    c->material = *m;      // read at the next swr_draw (by value into the kernel arguments)
+    return SWR_OK;
+}
+
+int swr_texture_upload(swr_context* c, const void* bgra8, int32_t width, int32_t height) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    if (!bgra8 || width <= 0 || height <= 0 || width > 16384 || height > 16384)
+        return fail(c, SWR_ERR_BAD_ARG, "swr_texture_upload: bad texture %dx%d", width, height);
+    HIP_TRY(c, hipSetDevice(c->device));
+    { int rcs = sync_streams(c); if (rcs) return rcs; }
+    int rc;
+    const size_t n = (size_t)width * (size_t)height;
+    if ((rc = ensure(c, c->texture_bytes, n * 4))) return rc;
+    if ((rc = ensure(c, c->texture, n * 16))) return rc;
+    HIP_TRY(c, hipMemcpyAsync(c->texture_bytes.p, bgra8, n * 4, hipMemcpyHostToDevice, c->stream));
+    launch_texture_to_float((const uint32_t*)c->texture_bytes.p, (int64_t)n, (float4*)c->texture.p, c->stream);
+    HIP_TRY(c, hipGetLastError());
+    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->tex_w = width; c->tex_h = height;
+    return SWR_OK;
 }
 
 int swr_target_set(swr_context* c, int64_t width, int64_t height, int64_t row_begin, int64_t row_end) {
@@ -432,6 +496,13 @@ int swr_draw_primitives(swr_context* c, const float transform[16], uint32_t flag
         return fail(c, SWR_ERR_NO_SCENE, "swr_draw needs swr_scene_upload and swr_target_set first");
     if (flags & ~(uint32_t)(SWR_FLAG_DEPTH_TEST | SWR_FLAG_NO_COLOR | SWR_FLAG_METAL_RULES))
         return fail(c, SWR_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
+    if (primitive_type == SWR_PRIMITIVE_TRIANGLE && !(flags & SWR_FLAG_NO_COLOR) &&
+        c->material.shader != SWR_SHADER_PASSTHROUGH) {
+        if (!c->has_attrs)
+            return fail(c, SWR_ERR_BAD_ARG, "the material needs vertex attributes (swr_scene_attributes)");
+        if (c->material.shader == SWR_SHADER_TEXTURED_PHONG && c->tex_w <= 0)
+            return fail(c, SWR_ERR_BAD_ARG, "the material needs a texture (swr_texture_upload)");
+    }
     HIP_TRY(c, hipSetDevice(c->device));
     memcpy(c->last_m, transform, sizeof c->last_m);
     c->last_flags = flags;
@@ -543,6 +614,10 @@ int swr_render(swr_context* c, const swr_render_pass* p) {
         return fail(c, SWR_ERR_BAD_ARG, "swr_render: colour/depth image pointer is NULL");
     int rc;
     if ((rc = swr_scene_upload(c, p->vertices, p->vertex_count, p->indices, p->index_count))) return rc;
+    // the pass carries its own fragment stage: NULL material = the reference's passthrough
+    if ((rc = swr_material_set(c, p->material))) return rc;
+    if (p->attributes && (rc = swr_scene_attributes(c, p->attributes, p->vertex_count))) return rc;
+    if (p->texture && (rc = swr_texture_upload(c, p->texture, p->tex_width, p->tex_height))) return rc;
     if ((rc = swr_target_set(c, p->width, p->height, 0, p->height))) return rc;
     if ((rc = swr_draw_primitives(c, p->transform, p->flags, p->primitive_type))) return rc;
     if (!(p->flags & SWR_FLAG_NO_COLOR) && (rc = swr_read_color(c, p->color))) return rc;

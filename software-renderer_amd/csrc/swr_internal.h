@@ -66,7 +66,11 @@ struct DeviceFrame {
     const float4* xyz;             // [nv] split positions
     const float4* rgb;             // [nv] split colours
     const uint32_t* idx32;         // [ni] narrowed indices
-    const float4* tri_rgb;         // [ni] colours de-indexed per primitive corner (48 B / triangle)
+    const float4* tri_rgb;         // [ni] colours de-indexed per primitive corner (48 B / triangle); lane 3 = v
+    const float4* tri_nrm;         // [ni] (nx,ny,nz,u) per primitive corner (extended fragment stage)
+    swr_material material;         // shader == SWR_SHADER_PASSTHROUGH: the reference's stage
+    const float4* texels;          // texture of swr_texture_upload, converted to (r,g,b,a) floats
+    int32_t tex_w, tex_h;
     int64_t vertex_count;
     int64_t ntri;
     GeomRec* geo;
@@ -92,6 +96,9 @@ void launch_validate_indices(const int64_t* indices, int64_t count, int64_t vert
                              uint32_t* counters, hipStream_t s);
 void launch_split_scene(const swr_vertex* v, int64_t nv, const int64_t* idx, int64_t ni, float4* xyz,
                         float4* rgb, uint32_t* idx32, float4* tri_rgb, hipStream_t s);
+void launch_split_attrs(const swr_vertex_attr* attrs, int64_t nv, const uint32_t* idx32, int64_t ni,
+                        float4* tri_nrm, float4* tri_rgb, hipStream_t s);
+void launch_texture_to_float(const uint32_t* bgra, int64_t n, float4* out, hipStream_t s);
 void launch_setup_bin(const DeviceFrame& f, hipStream_t s);
 void launch_scan(const DeviceFrame& f, hipStream_t s);
 void launch_fill(const DeviceFrame& f, hipStream_t s);

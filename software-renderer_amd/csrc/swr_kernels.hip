@@ -156,6 +156,31 @@ __global__ void k_split_scene(const swr_vertex* __restrict__ v, int64_t nv, cons
     }
 }
 
+// swr_texture_upload: Pixel (b,g,r,a bytes) -> (r,g,b,a) floats, channel / 255.0f (IEEE division, once).
+__global__ void k_texture_to_float(const uint32_t* __restrict__ bgra, int64_t n, float4* __restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const uint32_t t = bgra[i];
+        out[i] = make_float4((float)((t >> 16) & 0xFFu) / 255.0f, (float)((t >> 8) & 0xFFu) / 255.0f,
+                             (float)(t & 0xFFu) / 255.0f, (float)(t >> 24) / 255.0f);
+    }
+}
+
+// swr_scene_attributes: de-index the extra varyings per primitive corner like tri_rgb.
+// tri_nrm[i] = (nx, ny, nz, u); v rides in the padding lane of tri_rgb[i] (r, g, b, v).
+__global__ void k_split_attrs(const swr_vertex_attr* __restrict__ attrs, int64_t nv, const uint32_t* __restrict__ idx32,
+                              int64_t ni, float4* __restrict__ tri_nrm, float4* __restrict__ tri_rgb) {
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float4* ap = reinterpret_cast<const float4*>(attrs);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ni; i += stride) {
+        const int64_t ix = idx32[i];
+        if (ix >= nv) continue;                  // cannot happen: the scene upload validated the indices
+        const float4 n = ap[2 * ix], t = ap[2 * ix + 1];
+        tri_nrm[i] = make_float4(n.x, n.y, n.z, t.x);
+        tri_rgb[i].w = t.y;
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // k_setup_bin
 // ------------------------------------------------------------------------------------------
@@ -607,7 +632,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_bins(uint32_t* __restrict
 struct RasterArgs {
     const GeomRec* geo;
     const GeomFull* geo_full;
-    const float4* tri_rgb;      // [3*ntri] vertex colours of each primitive, de-indexed at upload
+    const float4* tri_rgb;      // [3*ntri] vertex colours of each primitive, de-indexed at upload (r,g,b,v)
+    const float4* tri_nrm;      // [3*ntri] (nx,ny,nz,u) — extended fragment stage only
+    FragmentUniforms fs;        // material + texture of the extended fragment stage
     const uint32_t* tile_start;
     const uint32_t* bins;
     const uint32_t* counters;
@@ -754,7 +781,8 @@ __device__ __forceinline__ float pull_f(int byte_addr, float v) {
 // METAL = the Metal path's rules (SWR_FLAG_METAL_RULES; Shaders.metal:123-167) on the same machinery:
 // the "span" of every row of the ROI is the ROI's x-range, the per-pixel maths is the `divider`
 // barycentric with the inside test, the store is bgra8Unorm.
-template <bool ZTEST, int VAR = 0, bool METAL = false>
+// EXT = the extended fragment stage (normal / uv varyings, fragment_shader(vin, uniforms)) at the resolve.
+template <bool ZTEST, int VAR = 0, bool METAL = false, bool EXT = false>
 __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster(RasterArgs a) {
     static_assert(!METAL || ZTEST, "the Metal rules always z-test");
     constexpr int SUPER = 2;   // dense steps whose owner search is done together
@@ -1111,7 +1139,7 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
         // neighbouring pixels usually share the winning primitive: its record, T() and vertex
         // colours are fetched / computed once per run of equal primitives
         uint32_t cached_prim = 0xFFFFFFFFu;
-        float4 q2 = make_float4(0, 0, 0, 0), q3 = q2, ca = q2, cb = q2, cc = q2;
+        float4 q2 = make_float4(0, 0, 0, 0), q3 = q2, ca = q2, cb = q2, cc = q2, na = q2, nb = q2, nc = q2;
         float cfx = 0.0f, cfy = 0.0f;
         MetalTri mt = {};
 #pragma unroll
@@ -1146,6 +1174,11 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
                             ca = a.tri_rgb[3 * (size_t)prim + 0];
                             cb = a.tri_rgb[3 * (size_t)prim + 1];
                             cc = a.tri_rgb[3 * (size_t)prim + 2];
+                            if (EXT) {
+                                na = a.tri_nrm[3 * (size_t)prim + 0];
+                                nb = a.tri_nrm[3 * (size_t)prim + 1];
+                                nc = a.tri_nrm[3 * (size_t)prim + 2];
+                            }
                         }
                     }
                     float w0, w1, w2;
@@ -1165,7 +1198,17 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
                         vin.color = make_float3(ca.x * w0 + cb.x * w1 + cc.x * w2,     // :266
                                                 ca.y * w0 + cb.y * w1 + cc.y * w2,
                                                 ca.z * w0 + cb.z * w1 + cc.z * w2);
-                        const float4 f = fragment_shader(vin);
+                        float4 f;
+                        if (EXT) {   // varyings interpolated like colour; u = tri_nrm.w, v = tri_rgb.w
+                            vin.normal = make_float3(na.x * w0 + nb.x * w1 + nc.x * w2,
+                                                     na.y * w0 + nb.y * w1 + nc.y * w2,
+                                                     na.z * w0 + nb.z * w1 + nc.z * w2);
+                            vin.uv = make_float2(na.w * w0 + nb.w * w1 + nc.w * w2,
+                                                 ca.w * w0 + cb.w * w1 + cc.w * w2);
+                            f = fragment_shader(vin, a.fs);
+                        } else {
+                            f = fragment_shader(vin);
+                        }
                         // Pixel(float3:) -> .floats(b: z, g: y, r: x, a: 1) truncates (:116-128);
                         // the Metal path's bgra8Unorm store rounds to nearest even
                         float ub = fminf(fmaxf(f.z, 0.0f), 1.0f) * 255.0f, ug = fminf(fmaxf(f.y, 0.0f), 1.0f) * 255.0f;
@@ -1312,6 +1355,17 @@ void launch_split_scene(const swr_vertex* v, int64_t nv, const int64_t* idx, int
     hipLaunchKernelGGL(k_split_scene, dim3(2048), dim3(256), 0, s, v, nv, idx, ni, xyz, rgb, idx32, tri_rgb);
 }
 
+void launch_split_attrs(const swr_vertex_attr* attrs, int64_t nv, const uint32_t* idx32, int64_t ni,
+                        float4* tri_nrm, float4* tri_rgb, hipStream_t s) {
+    if (nv <= 0 || ni <= 0) return;
+    hipLaunchKernelGGL(k_split_attrs, dim3(2048), dim3(256), 0, s, attrs, nv, idx32, ni, tri_nrm, tri_rgb);
+}
+
+void launch_texture_to_float(const uint32_t* bgra, int64_t n, float4* out, hipStream_t s) {
+    if (n <= 0) return;
+    hipLaunchKernelGGL(k_texture_to_float, dim3(2048), dim3(256), 0, s, bgra, n, out);
+}
+
 void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
     if (f.ntri <= 0) return;
     const SetupArgs a = make_setup_args(f);
@@ -1365,6 +1419,12 @@ void launch_sort_bins(const DeviceFrame& f, hipStream_t s) {
 void launch_raster(const DeviceFrame& f, hipStream_t s) {
     RasterArgs a;
     a.geo = f.geo; a.geo_full = f.geo_full; a.tri_rgb = f.tri_rgb;
+    a.tri_nrm = f.tri_nrm;
+    a.fs.shader = f.material.shader; a.fs.shininess_log2 = f.material.shininess_log2;
+    a.fs.light_dir = make_float3(f.material.light_dir[0], f.material.light_dir[1], f.material.light_dir[2]);
+    a.fs.half_dir = make_float3(f.material.half_dir[0], f.material.half_dir[1], f.material.half_dir[2]);
+    a.fs.ambient = f.material.ambient; a.fs.diffuse = f.material.diffuse; a.fs.specular = f.material.specular;
+    a.fs.texels = f.texels; a.fs.tex_w = f.tex_w; a.fs.tex_h = f.tex_h;
     a.tile_start = f.tile_start; a.bins = f.bins;
     a.counters = f.counters; a.capacity = f.capacity;
     a.color = (f.flags & SWR_FLAG_NO_COLOR) ? nullptr : f.color;
@@ -1372,8 +1432,17 @@ void launch_raster(const DeviceFrame& f, hipStream_t s) {
     a.tag_class = f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0;
     const unsigned tiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
     if (tiles == 0) return;
+    const bool ext = f.material.shader != SWR_SHADER_PASSTHROUGH && a.color != nullptr;
     if (f.flags & SWR_FLAG_METAL_RULES) {
-        hipLaunchKernelGGL((k_raster<true, 0, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        if (ext) hipLaunchKernelGGL((k_raster<true, 0, true, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        else hipLaunchKernelGGL((k_raster<true, 0, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        return;
+    }
+    if (ext) {
+        if (f.flags & SWR_FLAG_DEPTH_TEST)
+            hipLaunchKernelGGL((k_raster<true, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        else
+            hipLaunchKernelGGL((k_raster<false, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         return;
     }
     static const int variant = getenv("SWR_DEBUG_VARIANT") ? atoi(getenv("SWR_DEBUG_VARIANT")) : 0;

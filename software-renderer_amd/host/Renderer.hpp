@@ -101,7 +101,31 @@ struct matrix_float4x4 {
     }
 };
 
-// Renderer.swift:191-200
+// ---- fragment-stage extensions (not in the reference; include/swr.h swr_vertex_attr / swr_material) ----
+// Per-vertex normal + texture coordinate, parallel to RenderPass.vertices.
+struct VertexAttributes {
+    float normal[4];
+    float uv[4];
+    VertexAttributes() : normal{0, 0, 0, 0}, uv{0, 0, 0, 0} {}
+    VertexAttributes(float nx, float ny, float nz, float u, float v) : normal{nx, ny, nz, 0}, uv{u, v, 0, 0} {}
+};
+static_assert(sizeof(VertexAttributes) == sizeof(swr_vertex_attr), "VertexAttributes must match swr_vertex_attr");
+
+enum class Shader { passthrough = SWR_SHADER_PASSTHROUGH, phong = SWR_SHADER_PHONG,
+                    texturedPhong = SWR_SHADER_TEXTURED_PHONG };
+
+// What the Metal pipeline would bind as fragment-function arguments.
+struct Material {
+    Shader shader = Shader::passthrough;       // passthrough = Shaders.metal:116-121
+    int shininessLog2 = 5;                     // specular exponent 2^k
+    float lightDirection[3] = {0, 0, -1};      // unit, towards the light, in the space of the normals
+    float halfDirection[3] = {0, 0, -1};       // unit Blinn half vector
+    float ambient = 0.15f, diffuse = 0.8f, specular = 0.4f;
+    const Image<Pixel>* texture = nullptr;     // texturedPhong only; caller-owned b,g,r,a texels
+};
+
+// Renderer.swift:191-200 (+ the optional extended fragment stage: empty attributes / passthrough material
+// = the reference's RenderPass exactly)
 struct RenderPass {
     ColorImage colorBuffer;
     DepthImage depthBuffer;
@@ -109,6 +133,8 @@ struct RenderPass {
     std::vector<int64_t> indices;                       // Swift Int
     PrimitiveType primitiveType = PrimitiveType::triangle;
     matrix_float4x4 transform = matrix_float4x4::identity();
+    std::vector<VertexAttributes> attributes = {};
+    Material material = {};
 };
 
 namespace detail {
@@ -138,6 +164,26 @@ public:
         rp.flags = flags;
         for (int c = 0; c < 4; c++)
             for (int r = 0; r < 4; r++) rp.transform[4 * c + r] = p.transform.columns[c][r];
+        swr_material mat{};
+        if (p.material.shader != Shader::passthrough) {
+            if (p.attributes.size() != p.vertices.size())
+                throw RenderError(SWR_ERR_BAD_ARG, "RenderPass.attributes must have one entry per vertex");
+            mat.shader = (int32_t)p.material.shader;
+            mat.shininess_log2 = p.material.shininessLog2;
+            for (int k = 0; k < 3; k++) {
+                mat.light_dir[k] = p.material.lightDirection[k];
+                mat.half_dir[k] = p.material.halfDirection[k];
+            }
+            mat.ambient = p.material.ambient; mat.diffuse = p.material.diffuse; mat.specular = p.material.specular;
+            rp.attributes = reinterpret_cast<const swr_vertex_attr*>(p.attributes.data());
+            rp.material = &mat;
+            if (p.material.shader == Shader::texturedPhong) {
+                if (!p.material.texture) throw RenderError(SWR_ERR_BAD_ARG, "texturedPhong needs Material.texture");
+                rp.texture = p.material.texture->pointer;
+                rp.tex_width = (int32_t)p.material.texture->width;
+                rp.tex_height = (int32_t)p.material.texture->height;
+            }
+        }
         int rc = swr_render(ctx_, &rp);
         if (rc) throw RenderError(rc, swr_last_error(ctx_));
     }

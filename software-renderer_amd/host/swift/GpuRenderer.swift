@@ -14,6 +14,11 @@ final class GpuRenderer {
     var depthTest = true
     /// true: the Metal kernels' own rules (SWR_FLAG_METAL_RULES) instead of the CPU renderer's pixel rules.
     var metalRules = false
+    /// Extended fragment stage (not in the original app): per-vertex normals / uvs parallel to
+    /// renderPass.vertices, a material and an optional texture.  All nil = Shaders.metal:116-121.
+    var attributes: [swr_vertex_attr]? = nil
+    var material: swr_material? = nil
+    var texture: Image<Pixel>? = nil
 
     init() {
         var cfg = swr_config(device: -1, reserved: 0)
@@ -43,7 +48,22 @@ final class GpuRenderer {
                 pass.vertex_count = Int64(renderPass.vertices.count)
                 i.baseAddress!.withMemoryRebound(to: Int64.self, capacity: i.count) { pass.indices = $0 }
                 pass.index_count = Int64(i.count)
-                let rc = swr_render(ctx, &pass)
+                var mat = material ?? swr_material()
+                let attrs = attributes ?? []
+                let rc: Int32 = attrs.withUnsafeBufferPointer { a in
+                    withUnsafePointer(to: &mat) { m in
+                        if material != nil {
+                            precondition(attrs.count == renderPass.vertices.count)
+                            pass.attributes = a.baseAddress
+                            pass.material = m
+                            if let t = texture {
+                                pass.texture = UnsafeRawPointer(t.pointer)
+                                pass.tex_width = Int32(t.width); pass.tex_height = Int32(t.height)
+                            }
+                        }
+                        return swr_render(ctx, &pass)      // pointers are only used during the call
+                    }
+                }
                 precondition(rc == SWR_OK, String(cString: swr_last_error(ctx)))
             }
         }

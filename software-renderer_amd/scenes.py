@@ -48,6 +48,23 @@ def uniform01(seed: int, n: int, offset: int = 0) -> np.ndarray:
     return ((z >> np.uint64(40)).astype(np.float32)) * np.float32(1.0 / 16777216.0)
 
 
+SHADER_PASSTHROUGH, SHADER_PHONG, SHADER_TEXTURED_PHONG = 0, 1, 2
+
+
+@dataclass
+class Shading:
+    """The extended fragment stage of include/swr.h (swr_vertex_attr / swr_material / texture)."""
+    attrs: np.ndarray                       # float32 [nv, 8]: nx,ny,nz,_, u,v,_,_
+    shader: int = SHADER_PHONG
+    shininess_log2: int = 5
+    light_dir: tuple = (0.0, 0.0, -1.0)     # unit, towards the light, in the space of the normals
+    half_dir: tuple = (0.0, 0.0, -1.0)      # unit Blinn half vector
+    ambient: float = 0.15
+    diffuse: float = 0.8
+    specular: float = 0.4
+    texture: np.ndarray | None = None       # uint8 [th, tw, 4] b,g,r,a
+
+
 @dataclass
 class Scene:
     name: str
@@ -58,6 +75,7 @@ class Scene:
     transform: np.ndarray           # float32 [16], column-major
     flags: int = 0
     meta: dict = field(default_factory=dict)
+    shading: Shading | None = None
 
     @property
     def triangles(self) -> int:
@@ -136,6 +154,64 @@ def torus_mesh(nu: int, nv: int, major: float, minor: float):
     return xyz, rgb, idx
 
 
+def pack_attrs(normal: np.ndarray, uv: np.ndarray) -> np.ndarray:
+    a = np.zeros((normal.shape[0], 8), dtype=np.float32)
+    a[:, 0:3] = normal
+    a[:, 4:6] = uv
+    return a
+
+
+def torus_attrs(nu: int, nv: int, u_repeat: float = 8.0, v_repeat: float = 4.0) -> np.ndarray:
+    """Normals and texture coordinates of torus_mesh(nu, nv, ...), vertex for vertex."""
+    u = (np.arange(nu, dtype=np.float64) / nu)
+    v = (np.arange(nv, dtype=np.float64) / nv)
+    uu, vv = np.meshgrid(u, v, indexing="ij")
+    cx, sx = np.cos(2 * math.pi * uu), np.sin(2 * math.pi * uu)
+    cv, sv = np.cos(2 * math.pi * vv), np.sin(2 * math.pi * vv)
+    nrm = np.stack([cv * cx, cv * sx, sv], axis=-1).reshape(-1, 3)
+    uv = np.stack([uu * u_repeat, vv * v_repeat], axis=-1).reshape(-1, 2)
+    return pack_attrs(nrm.astype(np.float32), uv.astype(np.float32))
+
+
+def _unit(v) -> tuple:
+    a = np.asarray(v, dtype=np.float64)
+    a = a / np.linalg.norm(a)
+    return tuple(float(np.float32(x)) for x in a)
+
+
+def light_rig(light=(0.4, 0.6, -0.7), view=(0.0, 0.0, -1.0)):
+    """(light_dir, half_dir): unit vector towards a distant light and the Blinn half vector for a distant
+    viewer, both in the space of the normals."""
+    l = np.asarray(_unit(light)); v = np.asarray(_unit(view))
+    return _unit(l), _unit(l + v)
+
+
+def checker_texture(tw: int = 256, th: int = 256, seed: int = 0x7E57, cells: int = 8) -> np.ndarray:
+    """Procedural b,g,r,a texture: two-tone checker modulated by SplitMix64 noise (no asset files exist
+    in the reference or the container)."""
+    y, x = np.meshgrid(np.arange(th), np.arange(tw), indexing="ij")
+    chk = (((x * cells) // tw + (y * cells) // th) & 1).astype(np.float64)
+    noise = (splitmix64(seed, tw * th) >> np.uint64(56)).astype(np.float64).reshape(th, tw) / 255.0
+    t = np.zeros((th, tw, 4), dtype=np.uint8)
+    t[..., 0] = np.clip(255 * (0.25 + 0.6 * chk) * (0.7 + 0.3 * noise), 0, 255)          # b
+    t[..., 1] = np.clip(255 * (0.85 - 0.5 * chk) * (0.7 + 0.3 * noise), 0, 255)          # g
+    t[..., 2] = np.clip(255 * (0.35 + 0.6 * (x / tw)) * (0.7 + 0.3 * noise), 0, 255)     # r
+    t[..., 3] = 255
+    return t
+
+
+def random_shading(nv: int, seed: int, shader: int = SHADER_PHONG, texture: np.ndarray | None = None,
+                   shininess_log2: int = 4) -> Shading:
+    """Random normals (any length, a few exactly zero) and texture coordinates in [-2, 3) for parity tests."""
+    n = uniform01(seed ^ 0x5AD, 3 * nv).reshape(nv, 3) * np.float32(2.0) - np.float32(1.0)
+    n[:: 97] = 0.0
+    uv = uniform01(seed ^ 0x7EC, 2 * nv, 3 * nv).reshape(nv, 2) * np.float32(5.0) - np.float32(2.0)
+    l, h = light_rig()
+    if shader == SHADER_TEXTURED_PHONG and texture is None:
+        texture = checker_texture(64, 32, seed)
+    return Shading(pack_attrs(n, uv), shader, shininess_log2, l, h, 0.2, 0.7, 0.5, texture)
+
+
 # ---------------------------------------------------------------------------------------------
 def cfg1_triangle(gouraud: bool = False) -> Scene:
     """one triangle, identity transform, 256x256."""
@@ -194,6 +270,31 @@ def cfg4_soup(ntri: int = 1_000_000, width: int = 3840, height: int = 2160,
     return Scene("cfg4_soup", width, height, pack_vertices(xyz.reshape(-1, 3), rgb),
                  np.arange(3 * ntri, dtype=np.int64), identity(), flags,
                  {"r_ndc": r_ndc, "seed": seed})
+
+
+def cfg3_phong(**kw) -> Scene:
+    """BASELINE config 3 as named: the bunny-scale mesh with per-pixel Phong + z-buffer at 4K."""
+    sc = cfg3_bunny_scale(**kw)
+    nu, nv = (int(t) for t in sc.meta["mesh"].split()[1].split("x"))
+    l, h = light_rig()
+    sc.shading = Shading(torus_attrs(nu, nv), SHADER_PHONG, 5, l, h, 0.15, 0.8, 0.4, None)
+    sc.name = "cfg3_phong"
+    return sc
+
+
+def cfg5_textured(tex: int = 1024, **kw) -> Scene:
+    """BASELINE config 5 as named: the Sponza-scale grid, textured + Phong at 8K."""
+    sc = cfg5_sponza_scale(**kw)
+    xyz = sc.vertices[:, 0:3].astype(np.float64)
+    # analytic normals of z = z0 + 0.1 sin(3x) cos(2y) (before the per-wall xy scale; good enough for lighting)
+    nrm = np.stack([-0.3 * np.cos(3 * xyz[:, 0]) * np.cos(2 * xyz[:, 1]),
+                    0.2 * np.sin(3 * xyz[:, 0]) * np.sin(2 * xyz[:, 1]), -np.ones(xyz.shape[0])], axis=-1)
+    uv = xyz[:, 0:2] * 6.0
+    l, h = light_rig()
+    sc.shading = Shading(pack_attrs(nrm.astype(np.float32), uv.astype(np.float32)), SHADER_TEXTURED_PHONG, 4,
+                         l, h, 0.2, 0.8, 0.3, checker_texture(tex, tex))
+    sc.name = "cfg5_textured"
+    return sc
 
 
 def cfg5_sponza_scale(width: int = 7680, height: int = 4320, nx: int = 512, ny: int = 256) -> Scene:

@@ -38,7 +38,37 @@ def emit(name, scene, flags):
     return c, d, st
 
 
+def emit_shaded(name, scene, flags, sh, metal=False):
+    """Extended fragment stage (not in the reference; build-internal parity): oracle frame + its inputs."""
+    W, H = scene.width, scene.height
+    if metal:
+        c, d, st, rc = oracle.render_metal(scene.vertices, scene.indices, scene.transform, W, H, 0, shading=sh)
+        c2, d2 = swr_oracle_np.render_metal(scene.vertices, scene.indices, scene.transform, W, H, shading=sh)
+    else:
+        c, d, st, rc = oracle.render(scene.vertices, scene.indices, scene.transform, W, H, flags, shading=sh)
+        c2, d2, _ = swr_oracle_np.render(scene.vertices, scene.indices, scene.transform, W, H,
+                                         depth_test=bool(flags & 1), shading=sh)
+    assert rc == 0 and np.array_equal(c, c2) and d.tobytes() == d2.tobytes(), name
+    out = dict(vertices=scene.vertices, indices=scene.indices, transform=scene.transform, width=np.int64(W),
+               height=np.int64(H), flags=np.int64(flags), metal=np.int64(metal), color=c, depth=d,
+               attrs=sh.attrs, shader=np.int64(sh.shader), shininess_log2=np.int64(sh.shininess_log2),
+               light_dir=np.asarray(sh.light_dir, np.float32), half_dir=np.asarray(sh.half_dir, np.float32),
+               ads=np.asarray([sh.ambient, sh.diffuse, sh.specular], np.float32))
+    if sh.texture is not None:
+        out["texture"] = sh.texture
+    os.makedirs(os.path.join(HERE, "shaded"), exist_ok=True)
+    np.savez_compressed(os.path.join(HERE, "shaded", name + ".npz"), **out)
+    print(f"shaded/{name}: {scene.triangles} tris {W}x{H} flags={flags} metal={metal} shader={sh.shader}")
+
+
 def main():
+    torus = S.cfg3_phong(width=320, height=180, nu=16, nv=24, ntri=None)
+    emit_shaded("torus_phong_z", torus, 1, torus.shading)
+    emit_shaded("torus_phong_metal", torus, 0, torus.shading, metal=True)
+    grid = S.cfg5_textured(tex=32, width=256, height=144, nx=32, ny=16)
+    emit_shaded("grid_textured_z", grid, 1, grid.shading)
+    soup = S.random_soup(200, 192, 128, 0x5EED0200, r_ndc=0.2, margin=1.1)
+    emit_shaded("soup_textured_painter", soup, 0, S.random_shading(soup.vertices.shape[0], 0x5EED0201, 2))
     c, d, st = emit("cfg1_flat", S.cfg1_triangle(), 0)
     cov = c[..., 3] == 255
     assert cov.sum() == 8193 and (c[cov] == (63, 127, 255, 255)).all() and np.isposinf(d).all()   # SURVEY §C.1

@@ -70,9 +70,34 @@ int main() {
         CHECK(pass.colorBuffer.at(128, 128).b == 64 && pass.colorBuffer.at(128, 128).g == 128);
         CHECK(pass.depthBuffer.at(128, 128) == 0.5f);
 
+        // extended fragment stage (not in the reference): per-pixel Phong, then a 1x1 texture on the base colour.
+        // normal (0,0,-2), L = H = (0,0,-1): rgb = c * fl(0.1 + 0.5) + 0.25 -> (0.85, 0.55, 0.4) -> 216, 140, 102
+        pass.attributes = {VertexAttributes(0, 0, -2, 0, 0), VertexAttributes(0, 0, -2, 1, 0), VertexAttributes(0, 0, -2, 0, 1)};
+        pass.material.shader = Shader::phong;
+        pass.material.shininessLog2 = 3;
+        pass.material.ambient = 0.1f; pass.material.diffuse = 0.5f; pass.material.specular = 0.25f;
+        gpuRenderer.render(pass);
+        CHECK(pass.colorBuffer.at(128, 128).r == 216 && pass.colorBuffer.at(128, 128).g == 140 &&
+              pass.colorBuffer.at(128, 128).b == 102 && pass.colorBuffer.at(128, 128).a == 255);
+        Pixel texel{0, 128, 255, 255};      // b,g,r,a: base = c * (1, 128/255, 0)
+        pass.material.shader = Shader::texturedPhong;
+        const Image<Pixel> texture(&texel, 1, 1, 4);
+        pass.material.texture = &texture;
+        gpuRenderer.render(pass);
+        CHECK(pass.colorBuffer.at(128, 128).r == 216 && pass.colorBuffer.at(128, 128).g == 102 &&
+              pass.colorBuffer.at(128, 128).b == 63);
+        pass.attributes.pop_back();         // one attribute per vertex, or the mirror throws
+        bool threw = false;
+        try { gpuRenderer.render(pass); } catch (const RenderError& e) { threw = e.code == SWR_ERR_BAD_ARG; }
+        CHECK(threw);
+        pass.attributes.clear();
+        pass.material = Material{};         // back to Shaders.metal:116-121
+        gpuRenderer.render(pass);
+        CHECK(pass.colorBuffer.at(128, 128).r == 255 && pass.colorBuffer.at(128, 128).g == 127);
+
         // the reference traps on a bad index (Renderer.swift:226); the mirror throws
         pass.indices = {0, 1, 99};
-        bool threw = false;
+        threw = false;
         try { gpuRenderer.render(pass); } catch (const RenderError& e) { threw = e.code == SWR_ERR_INDEX_RANGE; }
         CHECK(threw);
         pass.primitiveType = PrimitiveType::line;   // stub in the reference (Renderer.swift:289-293): clears only

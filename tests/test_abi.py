@@ -48,8 +48,10 @@ def test_product_does_not_link_the_oracle(swr):
 def test_struct_layouts_match_the_swift_types(swr):
     """Vertex = 2 x SIMD3<Float> padded to 16 B (Renderer.swift:154-157); RenderPass fields."""
     B = swr.binding
-    assert ctypes.sizeof(B.RenderPass) == 8 * 10 + 4 + 4 + 64
+    assert ctypes.sizeof(B.RenderPass) == 8 * 10 + 4 + 4 + 64 + 3 * 8 + 2 * 4
     assert B.RenderPass.transform.offset == 88
+    assert B.RenderPass.attributes.offset == 152          # extended fragment stage (ABI 2)
+    assert ctypes.sizeof(B.Material) == 56
     assert ctypes.sizeof(B.Timings) == 5 * 4 + 4 + 3 * 8
 
 

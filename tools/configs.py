@@ -7,7 +7,9 @@ S = swr_amd.scenes
 for name, scene, flags in (("cfg2 torus 6320 tris 1080p painter", S.cfg2_teapot_scale(), 0),
                            ("cfg2 torus 6320 tris 1080p z-test", S.cfg2_teapot_scale(), 1),
                            ("cfg3 torus 69451 tris 4K z-test", S.cfg3_bunny_scale(), 1),
+                           ("cfg3 torus 69451 tris 4K per-pixel Phong + z", S.cfg3_phong(), 1),
                            ("cfg5 grid 262144 tris 8K z-test", S.cfg5_sponza_scale(), 1),
+                           ("cfg5 grid 262144 tris 8K textured + Phong + z", S.cfg5_textured(), 1),
                            ("big: 300 screen-filling tris 1080p z", S.random_soup(300, 1920, 1080, 91, r_ndc=1.5, flags=1, margin=0.5), 1),
                            ("cfg4 soup 1M tris 4K METAL rules (colour+depth)", S.cfg4_soup(depth_only=False), 4),
                            ("cfg4 soup 1M tris 4K CPU rules colour+depth", S.cfg4_soup(depth_only=False), 1),
@@ -21,6 +23,8 @@ for name, scene, flags in (("cfg2 torus 6320 tris 1080p painter", S.cfg2_teapot_
         v, i, W, H, m = scene.vertices, scene.indices, scene.width, scene.height, scene.transform
     with swr_amd.Context() as ctx:
         ctx.scene_upload(v, i); ctx.target_set(W, H)
+        if scene is not None and scene.shading is not None:
+            ctx.shading_set(scene.shading)
         for _ in range(5): ctx.draw(m, flags)
         ctx.sync()
         t0 = time.perf_counter()

@@ -36,6 +36,9 @@ struct swr_context {
 
     // scene (RenderPass.vertices / .indices)
     DevBuf vertices, indices, xyz, rgb, idx32, tri_rgb;
+    // the triangle stream built at upload (swr_upload.hip)
+    DevBuf tri_xyz, inv, box64, stream_scratch, sort_temp;
+    bool reordered = false;
     int64_t nv = 0, ni = 0;
     bool has_scene = false;
     // extended fragment stage (swr_scene_attributes / swr_material_set / swr_texture_upload)
@@ -53,6 +56,8 @@ struct swr_context {
     // while k_raster of frame N runs on `stream` (HBM-bound vs LDS/VALU-bound: they overlap well).
     struct Slot {
         DevBuf geo, geo_full, ranges, bins, bin_matrix;
+        DevBuf live;           // [2 counts][live stream-group ids] (k_cull_groups)
+        int live_parity = 0;
         DevBuf tilebuf;        // [CNT_WORDS counters][tiles tile_count][tiles+1 tile_start][tiles cursor]
         hipEvent_t bin_done = nullptr, ras_done = nullptr;
         bool ras_recorded = false;
@@ -146,6 +151,10 @@ DeviceFrame make_frame(swr_context* c, int si, const float m[16], uint32_t flags
     f.rgb = (const float4*)c->rgb.p;
     f.idx32 = (const uint32_t*)c->idx32.p;
     f.tri_rgb = (const float4*)c->tri_rgb.p;
+    f.tri_xyz = (const float4*)c->tri_xyz.p;
+    f.inv = (const uint32_t*)c->inv.p;
+    f.box64 = (const float4*)c->box64.p;
+    f.reordered = c->reordered ? 1 : 0;
     f.tri_nrm = (const float4*)c->tri_nrm.p;
     f.material = c->material;
     f.texels = (const float4*)c->texture.p;
@@ -163,6 +172,8 @@ DeviceFrame make_frame(swr_context* c, int si, const float m[16], uint32_t flags
     f.ranges = (uint2*)sl.ranges.p;
     f.plan = plan_binning(f.ntri, tiles_of(c->tg));
     f.bin_matrix = (uint32_t*)sl.bin_matrix.p;
+    f.live = (uint32_t*)sl.live.p;
+    f.live_parity = sl.live_parity;
     f.bins = (uint32_t*)sl.bins.p;
     f.capacity = c->capacity;
     f.color = (uint8_t*)c->color.p;
@@ -245,6 +256,7 @@ int enqueue_frame(swr_context* c) {
     }
     const bool all = c->timing >= 2;
     if (ev && all) HIP_TRY(c, hipEventRecord(ev[0], sb));
+    if (f.plan.use_lds && f.ntri > 0) sl.live_parity ^= 1;    // k_cull_groups zeroes the other count for the next use
     launch_setup_bin(f, sb);
     if (ev && all) HIP_TRY(c, hipEventRecord(ev[1], sb));
     launch_scan(f, sb);
@@ -337,10 +349,10 @@ void swr_context_destroy(swr_context* c) {
     hipSetDevice(c->device);
     if (c->bin_stream) hipStreamSynchronize(c->bin_stream);
     if (c->stream) hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->xyz, &c->rgb, &c->idx32, &c->tri_rgb, &c->attrs, &c->tri_nrm, &c->texture, &c->texture_bytes, &c->color, &c->depth};
+    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->xyz, &c->rgb, &c->idx32, &c->tri_rgb, &c->tri_xyz, &c->inv, &c->box64, &c->stream_scratch, &c->sort_temp, &c->attrs, &c->tri_nrm, &c->texture, &c->texture_bytes, &c->color, &c->depth};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& sl : c->slot) {
-        DevBuf* sb[] = {&sl.geo, &sl.geo_full, &sl.ranges, &sl.bins, &sl.bin_matrix, &sl.tilebuf};
+        DevBuf* sb[] = {&sl.geo, &sl.geo_full, &sl.ranges, &sl.bins, &sl.bin_matrix, &sl.live, &sl.tilebuf};
         for (DevBuf* b : sb) if (b->p) hipFree(b->p);
         if (sl.bin_done) hipEventDestroy(sl.bin_done);
         if (sl.ras_done) hipEventDestroy(sl.ras_done);
@@ -373,10 +385,22 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     if ((rc = ensure(c, c->rgb, (size_t)vertex_count * 16))) return rc;
     if ((rc = ensure(c, c->idx32, (size_t)index_count * 4))) return rc;
     if ((rc = ensure(c, c->tri_rgb, (size_t)index_count * 16))) return rc;
+    const int64_t ntri = index_count / 3;
+    static const bool sort_on = !(getenv("SWR_SORT") && atoi(getenv("SWR_SORT")) == 0);
+    const bool reorder = sort_on && ntri > 1 && ntri < SORT_MAX_TRIS;
+    const size_t sort_bytes = reorder ? stream_sort_temp_bytes(ntri) : 0;
+    if ((rc = ensure(c, c->tri_xyz, (size_t)index_count * 16))) return rc;
+    if ((rc = ensure(c, c->inv, (size_t)ntri * 4))) return rc;
+    if ((rc = ensure(c, c->box64, (size_t)((ntri + 63) / 64) * 32))) return rc;
+    if ((rc = ensure(c, c->stream_scratch, ((size_t)ntri * 4 + 8) * 4))) return rc;
+    if ((rc = ensure(c, c->sort_temp, sort_bytes))) return rc;
     for (auto& sl : c->slot) {
         if ((rc = ensure(c, sl.geo, (size_t)(index_count / 3) * sizeof(GeomRec)))) return rc;
         if ((rc = ensure(c, sl.geo_full, (size_t)(index_count / 3) * sizeof(GeomFull)))) return rc;
         if ((rc = ensure(c, sl.ranges, (size_t)(index_count / 3) * sizeof(uint2)))) return rc;
+        if ((rc = ensure(c, sl.live, (size_t)(2 + (index_count / 3 + 63) / 64) * 4))) return rc;
+        HIP_TRY(c, hipMemsetAsync(sl.live.p, 0, 8, c->stream));     // both frame counts start at zero
+        sl.live_parity = 0;
         if ((rc = ensure(c, sl.tilebuf, (size_t)(CNT_WORDS + 3 * std::max(1, tiles_of(c->tg)) + 1) * 4))) return rc;
     }
     if (vertex_count)
@@ -388,8 +412,21 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     HIP_TRY(c, hipMemsetAsync(c->slot[0].tilebuf.p, 0, CNT_WORDS * 4, c->stream));
     launch_validate_indices((const int64_t*)c->indices.p, index_count, vertex_count, (uint32_t*)c->slot[0].tilebuf.p, c->stream);
     launch_split_scene((const swr_vertex*)c->vertices.p, vertex_count, (const int64_t*)c->indices.p, index_count,
-                       (float4*)c->xyz.p, (float4*)c->rgb.p, (uint32_t*)c->idx32.p, (float4*)c->tri_rgb.p, c->stream);
+                       (float4*)c->xyz.p, (float4*)c->rgb.p, (uint32_t*)c->idx32.p, c->stream);
     HIP_TRY(c, hipGetLastError());
+    {
+        StreamBuild b{};
+        b.vertices = (const swr_vertex*)c->vertices.p; b.nv = vertex_count;
+        b.indices = (const int64_t*)c->indices.p; b.ntri = ntri;
+        b.xyz = (const float4*)c->xyz.p;
+        b.sort = reorder;
+        b.scratch = (uint32_t*)c->stream_scratch.p;
+        b.sort_temp = c->sort_temp.p; b.sort_temp_bytes = sort_bytes;
+        b.tri_xyz = (float4*)c->tri_xyz.p; b.tri_rgb = (float4*)c->tri_rgb.p;
+        b.inv = (uint32_t*)c->inv.p; b.box64 = (float4*)c->box64.p;
+        HIP_TRY(c, launch_build_stream(b, c->stream));
+        c->reordered = ntri > 0 && ntri < SORT_MAX_TRIS;   // original index travels in GeomRec.flags
+    }
     HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->slot[0].tilebuf.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     if (c->h_counters[CNT_BAD_INDEX])
@@ -415,8 +452,8 @@ int swr_scene_attributes(swr_context* c, const swr_vertex_attr* attributes, int6
     if (vertex_count)
         HIP_TRY(c, hipMemcpyAsync(c->attrs.p, attributes, (size_t)vertex_count * sizeof(swr_vertex_attr),
                                   hipMemcpyHostToDevice, c->stream));
-    launch_split_attrs((const swr_vertex_attr*)c->attrs.p, vertex_count, (const uint32_t*)c->idx32.p, c->ni,
-                       (float4*)c->tri_nrm.p, (float4*)c->tri_rgb.p, c->stream);
+    launch_gather_attrs((const swr_vertex_attr*)c->attrs.p, vertex_count, (const int64_t*)c->indices.p, c->ni / 3,
+                        (const float4*)c->tri_xyz.p, (float4*)c->tri_nrm.p, (float4*)c->tri_rgb.p, c->stream);
     HIP_TRY(c, hipGetLastError());
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     c->has_attrs = true;

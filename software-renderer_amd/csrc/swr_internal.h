@@ -37,8 +37,11 @@ static_assert(sizeof(GeomFull) == 32, "GeomFull must be 32 bytes");
 enum : uint32_t {
     GEOM_VALID = 1u << 0,
     GEOM_SMALL = 1u << 1,          // bbox extents < 2^15: int16 deltas and 32-bit span arithmetic are exact
-    GEOM_ORD_SHIFT = 2             // 3 x 2 bits: which of a,b,c is S0,S1,S2 of the y-sorted list (:271)
+    GEOM_ORD_SHIFT = 2,            // 3 x 2 bits: which of a,b,c is S0,S1,S2 of the y-sorted list (:271)
+    GEOM_ORIG_SHIFT = 8            // bits 8..31: the primitive's ORIGINAL index (scenes below 2^24 primitives;
+                                   // larger scenes are not reordered, so slot == original index)
 };
+constexpr int64_t SORT_MAX_TRIS = 1ll << 24;
 
 struct Target {
     int32_t width, height;         // full framebuffer
@@ -66,7 +69,12 @@ struct DeviceFrame {
     const float4* xyz;             // [nv] split positions
     const float4* rgb;             // [nv] split colours
     const uint32_t* idx32;         // [ni] narrowed indices
-    const float4* tri_rgb;         // [ni] colours de-indexed per primitive corner (48 B / triangle); lane 3 = v
+    // the triangle stream (swr_upload.hip): primitives in Morton order of their centroid, de-indexed
+    const float4* tri_xyz;         // [ni] corner positions; w of corner 0 = original primitive index (bits)
+    const uint32_t* inv;           // [ntri] sorted slot of original primitive o
+    const float4* box64;           // [2 * ceil(ntri/64)] object-space min / max of each 64-slot group
+    int32_t reordered;             // 1: slots are a permutation (original index in GeomRec.flags); 0: slot == index
+    const float4* tri_rgb;         // [ni] colours per slot corner (48 B / triangle); lane 3 = v
     const float4* tri_nrm;         // [ni] (nx,ny,nz,u) per primitive corner (extended fragment stage)
     swr_material material;         // shader == SWR_SHADER_PASSTHROUGH: the reference's stage
     const float4* texels;          // texture of swr_texture_upload, converted to (r,g,b,a) floats
@@ -83,6 +91,8 @@ struct DeviceFrame {
     uint2* ranges;                 // [ntri] band-clipped pixel bbox (x0|x1<<16, y0|y1<<16, y band-relative)
     uint32_t* bins;                // [capacity] primitive ids grouped by tile
     uint32_t* bin_matrix;          // [G][tiles] per-workgroup tile counts -> prefixes (LDS path)
+    uint32_t* live;                // [2 + ceil(ntri/64)] live stream groups of the frame (k_cull_groups)
+    int32_t live_parity;           // which of live[0] / live[1] is this frame's count
     BinPlan plan;
     uint32_t capacity;
     uint8_t* color;
@@ -95,9 +105,22 @@ struct DeviceFrame {
 void launch_validate_indices(const int64_t* indices, int64_t count, int64_t vertex_count,
                              uint32_t* counters, hipStream_t s);
 void launch_split_scene(const swr_vertex* v, int64_t nv, const int64_t* idx, int64_t ni, float4* xyz,
-                        float4* rgb, uint32_t* idx32, float4* tri_rgb, hipStream_t s);
-void launch_split_attrs(const swr_vertex_attr* attrs, int64_t nv, const uint32_t* idx32, int64_t ni,
-                        float4* tri_nrm, float4* tri_rgb, hipStream_t s);
+                        float4* rgb, uint32_t* idx32, hipStream_t s);
+
+// swr_upload.hip: the once-per-scene triangle stream
+struct StreamBuild {
+    const swr_vertex* vertices; int64_t nv;
+    const int64_t* indices; int64_t ntri;
+    const float4* xyz;             // split positions (for the bounds / Morton pass)
+    bool sort;                     // false: identity order (scenes of 2^24 primitives or more, or SWR_SORT=0)
+    uint32_t* scratch;             // 4 * ntri + 8 words
+    void* sort_temp; size_t sort_temp_bytes;
+    float4* tri_xyz; float4* tri_rgb; uint32_t* inv; float4* box64;
+};
+size_t stream_sort_temp_bytes(int64_t ntri);
+hipError_t launch_build_stream(const StreamBuild& b, hipStream_t s);
+void launch_gather_attrs(const swr_vertex_attr* attrs, int64_t nv, const int64_t* indices, int64_t ntri,
+                         const float4* tri_xyz, float4* tri_nrm, float4* tri_rgb, hipStream_t s);
 void launch_texture_to_float(const uint32_t* bgra, int64_t n, float4* out, hipStream_t s);
 void launch_setup_bin(const DeviceFrame& f, hipStream_t s);
 void launch_scan(const DeviceFrame& f, hipStream_t s);

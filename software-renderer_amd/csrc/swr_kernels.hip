@@ -139,21 +139,15 @@ __global__ void k_validate_indices(const int64_t* __restrict__ idx, int64_t n, i
 // so the per-frame setup kernel streams 60 MB instead of 120 MB at 1 M triangles.
 __global__ void k_split_scene(const swr_vertex* __restrict__ v, int64_t nv, const int64_t* __restrict__ idx,
                               int64_t ni, float4* __restrict__ xyz, float4* __restrict__ rgb,
-                              uint32_t* __restrict__ idx32, float4* __restrict__ tri_rgb) {
+                              uint32_t* __restrict__ idx32) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const float4* vp = reinterpret_cast<const float4*>(v);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
         xyz[i] = vp[2 * i];
         rgb[i] = vp[2 * i + 1];
     }
-    // tri_rgb: the three vertex colours of primitive p, de-indexed into one 48-byte record, so the
-    // resolve fetches them with one gather instead of idx32 -> rgb (two dependent levels, six lines).
-    // The index range is validated by k_validate_indices in the same upload; a bad index reads nothing.
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ni; i += stride) {
-        const int64_t ix = idx[i];
-        idx32[i] = (uint32_t)ix;
-        tri_rgb[i] = (ix >= 0 && ix < nv) ? vp[2 * ix + 1] : make_float4(0, 0, 0, 0);
-    }
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ni; i += stride)
+        idx32[i] = (uint32_t)idx[i];
 }
 
 // swr_texture_upload: Pixel (b,g,r,a bytes) -> (r,g,b,a) floats, channel / 255.0f (IEEE division, once).
@@ -166,28 +160,14 @@ __global__ void k_texture_to_float(const uint32_t* __restrict__ bgra, int64_t n,
     }
 }
 
-// swr_scene_attributes: de-index the extra varyings per primitive corner like tri_rgb.
-// tri_nrm[i] = (nx, ny, nz, u); v rides in the padding lane of tri_rgb[i] (r, g, b, v).
-__global__ void k_split_attrs(const swr_vertex_attr* __restrict__ attrs, int64_t nv, const uint32_t* __restrict__ idx32,
-                              int64_t ni, float4* __restrict__ tri_nrm, float4* __restrict__ tri_rgb) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const float4* ap = reinterpret_cast<const float4*>(attrs);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ni; i += stride) {
-        const int64_t ix = idx32[i];
-        if (ix >= nv) continue;                  // cannot happen: the scene upload validated the indices
-        const float4 n = ap[2 * ix], t = ap[2 * ix + 1];
-        tri_nrm[i] = make_float4(n.x, n.y, n.z, t.x);
-        tri_rgb[i].w = t.y;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // k_setup_bin
 // ------------------------------------------------------------------------------------------
 struct SetupArgs {
-    const float4* xyz;      // [nv] positions (w unused), split from the AoS Vertex at upload
-    const float4* rgb;      // [nv] colours
-    const uint32_t* idx32;  // [3*ntri] indices narrowed to 32 bits at upload
+    const float4* tri_xyz;  // [3*ntri] the triangle stream (swr_upload.hip): corner positions per sorted slot
+    const float4* box64;    // [2*ceil(ntri/64)] object-space box of every 64-slot group
+    int reordered;          // slots are a permutation of the primitives: original index -> GeomRec.flags
+    int cull;               // test the group boxes against the band
     int64_t ntri;
     GeomRec* geo;
     GeomFull* geo_full;
@@ -240,11 +220,9 @@ __device__ __forceinline__ void decode_vertices(const GeomFull* __restrict__ ful
 __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
     uint2 range = make_uint2(RANGE_NONE_X, 0u);
 
-    // :223-227 — three vertex references of primitive p, in index order
-    const uint32_t i0 = a.idx32[3 * p + 0];
-    const uint32_t i1 = a.idx32[3 * p + 1];
-    const uint32_t i2 = a.idx32[3 * p + 2];
-    const float4 xa = a.xyz[i0], xb = a.xyz[i1], xc = a.xyz[i2];
+    // :223-227 — the three vertex references of the primitive in slot p, in index order (de-indexed at upload)
+    const float4 xa = a.tri_xyz[3 * p + 0], xb = a.tri_xyz[3 * p + 1], xc = a.tri_xyz[3 * p + 2];
+    const uint32_t orig = a.reordered ? __float_as_uint(xa.w) : 0u;
     // vertex colours are passed through by vertex_shader untouched (Shaders.metal:53) and are only
     // consumed by the resolve, which fetches them for the winning primitive through idx32 / rgb
     const float4 ca = make_float4(0, 0, 0, 0), cb = ca, cc = ca;
@@ -311,7 +289,7 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
     }
     // int16 vertex deltas and 32-bit span arithmetic are exact when the bbox extents are < 2^15
     const bool small = ((int64_t)maxx - (int64_t)minx < 32768) && ((int64_t)s2y - (int64_t)s0y < 32768);
-    const uint32_t flags = (ok ? GEOM_VALID : 0u) | (small ? GEOM_SMALL : 0u) |
+    const uint32_t flags = (orig << GEOM_ORIG_SHIFT) | (ok ? GEOM_VALID : 0u) | (small ? GEOM_SMALL : 0u) |
                            ((uint32_t)o0 << GEOM_ORD_SHIFT) | ((uint32_t)o1 << (GEOM_ORD_SHIFT + 2)) |
                            ((uint32_t)o2 << (GEOM_ORD_SHIFT + 4));
 
@@ -392,23 +370,89 @@ __device__ __forceinline__ void for_each_tile(const PixBox& b, uint32_t p, F&& f
 constexpr int BIN_THREADS = 1024;  // workgroup size of k_setup_hist / k_fill_lds (512 measured no better beside raster workgroups)
 
 // ---- binning, LDS path (default): no global atomics ------------------------------------------
+// Can the 64 primitives of stream group `g` be skipped by this band?  True only when the projection of
+// the group's object-space box provably misses [0,W) x [row_begin,row_end): all eight corners in front of
+// the eye (w > 0, so the projected box is the hull of the projected corners), the hull at least `margin`
+// pixels outside, where margin = 1 px (truncation / rounding of :251 / Shaders.metal:71 can move a vertex
+// by less than one pixel) + a bound on the rounding error of the per-vertex transform (Σ|m_ij·c_j| terms at
+// 2^-20 relative, propagated through the divide) + 2^-18 of the coordinate itself.  NaN anywhere (a
+// non-finite vertex poisons its box) makes every comparison false: not culled.  Wave-uniform.
+__device__ __forceinline__ bool group_culled(const SetupArgs& a, int64_t g) {
+    const float4 lo = a.box64[2 * g], hi = a.box64[2 * g + 1];
+    const float fw = (float)a.tg.width, fh = (float)a.tg.height;
+    // error scale of one transformed coordinate: Σ_j |m_ij| * max|c_j| + |m_i3|
+    const float ax = fmaxf(fabsf(lo.x), fabsf(hi.x)), ay = fmaxf(fabsf(lo.y), fabsf(hi.y)), az = fmaxf(fabsf(lo.z), fabsf(hi.z));
+    const float4 c0 = a.m.columns[0], c1 = a.m.columns[1], c2 = a.m.columns[2], c3 = a.m.columns[3];
+    const float d = 9.5367431640625e-07f;   // 2^-20
+    const float ex = d * (fabsf(c0.x) * ax + fabsf(c1.x) * ay + fabsf(c2.x) * az + fabsf(c3.x));
+    const float ey = d * (fabsf(c0.y) * ax + fabsf(c1.y) * ay + fabsf(c2.y) * az + fabsf(c3.y));
+    const float ew = d * (fabsf(c0.w) * ax + fabsf(c1.w) * ay + fabsf(c2.w) * az + fabsf(c3.w));
+    float wmin = INFINITY, nxlo = INFINITY, nxhi = -INFINITY, nylo = INFINITY, nyhi = -INFINITY;
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const float x = (k & 1) ? hi.x : lo.x, y = (k & 2) ? hi.y : lo.y, z = (k & 4) ? hi.z : lo.z;
+        const float cx = c0.x * x + c1.x * y + c2.x * z + c3.x;
+        const float cy = c0.y * x + c1.y * y + c2.y * z + c3.y;
+        const float cw = c0.w * x + c1.w * y + c2.w * z + c3.w;
+        ok = ok && (cw - 2.0f * ew > 0.0f) && fabsf(cx) < INFINITY && fabsf(cy) < INFINITY && cw < INFINITY;
+        wmin = fminf(wmin, cw);
+        const float nx = cx / cw, ny = cy / cw;
+        nxlo = fminf(nxlo, nx); nxhi = fmaxf(nxhi, nx);
+        nylo = fminf(nylo, ny); nyhi = fmaxf(nyhi, ny);
+    }
+    if (!ok) return false;
+    const float wsafe = wmin - 2.0f * ew;                    // > 0
+    const float nmax = fmaxf(fmaxf(fabsf(nxlo), fabsf(nxhi)), fmaxf(fabsf(nylo), fabsf(nyhi)));
+    const float endc = (ex + ey + (1.0f + nmax) * ew) / wsafe + 4e-6f * (1.0f + nmax);   // |ndc error| bound
+    // screen = (ndc * +-0.5 + 0.5) * size
+    const float sx0 = (nxlo * 0.5f + 0.5f) * fw, sx1 = (nxhi * 0.5f + 0.5f) * fw;
+    const float sy0 = (nyhi * -0.5f + 0.5f) * fh, sy1 = (nylo * -0.5f + 0.5f) * fh;
+    const float smax = fmaxf(fmaxf(fabsf(sx0), fabsf(sx1)), fmaxf(fabsf(sy0), fabsf(sy1)));
+    const float margin = 1.0f + endc * fmaxf(fw, fh) + smax * 3.8146972656e-06f + 0.25f;
+    if (!(margin < INFINITY)) return false;
+    return sx1 + margin < 0.0f || sx0 - margin >= fw || sy1 + margin < (float)a.tg.row_begin ||
+           sy0 - margin >= (float)a.tg.row_end;
+}
+
 // Workgroup g owns the contiguous chunk [g*chunk, (g+1)*chunk) of the primitives in BOTH walks.
 // k_setup_hist: per-workgroup tile histogram in LDS (ds_add), written as row g of the matrix
 // M[G][tiles].  k_colscan turns every column into an exclusive prefix over g and emits the
 // per-tile totals; k_scan scans the totals; k_fill_lds seeds its LDS cursors with
 // tile_start[t] + M[g][t] and hands out bin positions with returning LDS atomics.
+// First kernel of a frame: the list of stream groups this band has to look at.  live[0] / live[1] are the
+// counts of this frame and of the slot's next frame (the roles swap every frame, `parity` says which is
+// which): this kernel appends to its own count — zeroed one frame earlier — and zeroes the other one, so no
+// memset is ever enqueued.  live[2..] = group ids, in no particular order (the image does not depend on it).
+__global__ __launch_bounds__(256) void k_cull_groups(SetupArgs a, uint32_t* __restrict__ live, int parity) {
+    const int64_t groups = (a.ntri + 63) >> 6;
+    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (g == 0) live[1 - parity] = 0u;
+    const bool keep = g < groups && !(a.cull && group_culled(a, g));
+    const unsigned long long mask = __ballot(keep);
+    const int lane = threadIdx.x & 63;
+    uint32_t base = 0u;
+    if (lane == 0 && mask) base = atomicAdd(&live[parity], (uint32_t)__popcll(mask));
+    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+    if (keep) live[2 + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)g;
+}
+
+// Live group j of the frame goes to wave (j / G) % 16 of workgroup j % G, then round-robin: neighbouring
+// groups (neighbours on screen, since the stream is Morton-ordered) land in different workgroups, so a
+// band's few live groups spread over the whole GPU and one workgroup's LDS histogram is not hammered on
+// one tile.  k_setup_hist and k_fill_lds walk the same list with the same mapping.
 __global__ __launch_bounds__(BIN_THREADS) void k_setup_hist(SetupArgs a, uint32_t* __restrict__ M,
-                                                     int chunk, int ntiles) {
+                                                     const uint32_t* __restrict__ live, int parity, int ntiles) {
     extern __shared__ uint32_t hist[];
     for (int e = threadIdx.x; e < ntiles; e += blockDim.x) hist[e] = 0u;
     __syncthreads();
-    const int64_t p0 = (int64_t)blockIdx.x * chunk;
-    const int64_t p1 = min(p0 + (int64_t)chunk, a.ntri);
     const int tiles_x = a.tg.tiles_x;
-    for (int64_t pw = p0; pw < p1; pw += blockDim.x) {          // wave-uniform trip count
-        const int64_t p = pw + threadIdx.x;
+    const uint32_t nlive = live[parity];
+    const uint32_t G = gridDim.x;
+    for (uint32_t j = (threadIdx.x >> 6) * G + blockIdx.x; j < nlive; j += G * (BIN_THREADS / 64)) {   // per wave
+        const int64_t p = ((int64_t)live[2 + j] << 6) + (threadIdx.x & 63);
         uint2 r = make_uint2(RANGE_NONE_X, 0u);
-        if (p < p1) {
+        if (p < a.ntri) {
             r = setup_triangle(a, p);
             a.ranges[p] = r;
         }
@@ -458,7 +502,8 @@ __global__ __launch_bounds__(BIN_THREADS) void k_fill_lds(const uint2* __restric
                                                    uint32_t* __restrict__ counters,
                                                    uint32_t* __restrict__ host_counters,
                                                    uint32_t* __restrict__ bins, uint32_t capacity,
-                                                   int chunk, int ntiles, int tiles_x, int tag_class) {
+                                                   const uint32_t* __restrict__ live, int parity,
+                                                   int ntiles, int tiles_x, int tag_class) {
     extern __shared__ uint32_t lds[];
     uint32_t* cursor = lds;             // [ntiles]
     uint32_t* part = lds + ntiles;      // [BIN_THREADS]
@@ -496,11 +541,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_fill_lds(const uint2* __restric
     const uint32_t* row = M + (size_t)blockIdx.x * (size_t)ntiles;
     for (int e = t; e < ntiles; e += BIN_THREADS) cursor[e] += row[e];
     __syncthreads();
-    const int64_t p0 = (int64_t)blockIdx.x * chunk;
-    const int64_t p1 = min(p0 + (int64_t)chunk, ntri);
-    for (int64_t pw = p0; pw < p1; pw += BIN_THREADS) {                // wave-uniform trip count
-        const int64_t p = pw + t;
-        const uint2 r = p < p1 ? ranges[p] : make_uint2(RANGE_NONE_X, 0u);
+    const uint32_t nlive = live[parity];
+    const uint32_t G = gridDim.x;
+    for (uint32_t j = (t >> 6) * G + blockIdx.x; j < nlive; j += G * (BIN_THREADS / 64)) {   // same walk as k_setup_hist
+        const int64_t p = ((int64_t)live[2 + j] << 6) + (t & 63);
+        const uint2 r = p < ntri ? ranges[p] : make_uint2(RANGE_NONE_X, 0u);
         for_each_tile(unpack_box(r), (uint32_t)p, [&](const PixBox& b, uint32_t prim, int tx, int ty) {
             const uint32_t pos = atomicAdd(&cursor[ty * tiles_x + tx], 1u);
             bins[pos] = prim | (tag_class ? size_class(b, tx, ty) << CLASS_SHIFT : 0u);
@@ -632,7 +677,9 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_bins(uint32_t* __restrict
 struct RasterArgs {
     const GeomRec* geo;
     const GeomFull* geo_full;
-    const float4* tri_rgb;      // [3*ntri] vertex colours of each primitive, de-indexed at upload (r,g,b,v)
+    const uint32_t* inv;        // [ntri] original primitive index -> stream slot (resolve; only when reordered)
+    int reordered;              // bin entries are stream slots; keys carry the original index from GeomRec.flags
+    const float4* tri_rgb;      // [3*ntri] vertex colours per slot corner, de-indexed at upload (r,g,b,v)
     const float4* tri_nrm;      // [3*ntri] (nx,ny,nz,u) — extended fragment stage only
     FragmentUniforms fs;        // material + texture of the extended fragment stage
     const uint32_t* tile_start;
@@ -877,6 +924,8 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
             } else {
                 load_tri(a.geo_full, prim, q0, q1, t, minx, maxx);
             }
+            // visibility keys order by the ORIGINAL primitive index (Renderer.swift:222,258)
+            if (a.reordered) t.prim = __float_as_uint(q1.w) >> GEOM_ORIG_SHIFT;
             ya = max(t.ch.s0y, Y0);
             yb = min(t.ch.s2y, Y1);
             bxa = max(minx, X0);
@@ -1138,7 +1187,7 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
         float dpix[4];
         // neighbouring pixels usually share the winning primitive: its record, T() and vertex
         // colours are fetched / computed once per run of equal primitives
-        uint32_t cached_prim = 0xFFFFFFFFu;
+        uint32_t cached_prim = 0xFFFFFFFFu, slot = 0u;
         float4 q2 = make_float4(0, 0, 0, 0), q3 = q2, ca = q2, cb = q2, cc = q2, na = q2, nb = q2, nc = q2;
         float cfx = 0.0f, cfy = 0.0f;
         MetalTri mt = {};
@@ -1160,7 +1209,8 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
                         cached_prim = prim;
                         int4 g0;
                         int vx[3], vy[3];
-                        load_vertices(a.geo, a.geo_full, prim, g0, q3, vx, vy);
+                        slot = a.reordered ? a.inv[prim] : prim;
+                        load_vertices(a.geo, a.geo_full, slot, g0, q3, vx, vy);
                         if (METAL) {
                             metal_consts(vx, vy, q3.x, q3.y, q3.z, mt);
                         } else {
@@ -1171,13 +1221,13 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
                         }
                         if (want_color) {
                             // vertex colours of a,b,c (RenderPass.vertices[RenderPass.indices[3p+k]].color), one 48-B record
-                            ca = a.tri_rgb[3 * (size_t)prim + 0];
-                            cb = a.tri_rgb[3 * (size_t)prim + 1];
-                            cc = a.tri_rgb[3 * (size_t)prim + 2];
+                            ca = a.tri_rgb[3 * (size_t)slot + 0];
+                            cb = a.tri_rgb[3 * (size_t)slot + 1];
+                            cc = a.tri_rgb[3 * (size_t)slot + 2];
                             if (EXT) {
-                                na = a.tri_nrm[3 * (size_t)prim + 0];
-                                nb = a.tri_nrm[3 * (size_t)prim + 1];
-                                nc = a.tri_nrm[3 * (size_t)prim + 2];
+                                na = a.tri_nrm[3 * (size_t)slot + 0];
+                                nb = a.tri_nrm[3 * (size_t)slot + 1];
+                                nc = a.tri_nrm[3 * (size_t)slot + 2];
                             }
                         }
                     }
@@ -1323,7 +1373,9 @@ void launch_validate_indices(const int64_t* indices, int64_t count, int64_t vert
 
 static SetupArgs make_setup_args(const DeviceFrame& f) {
     SetupArgs a;
-    a.xyz = f.xyz; a.rgb = f.rgb; a.idx32 = f.idx32; a.ntri = f.ntri;
+    a.tri_xyz = f.tri_xyz; a.box64 = f.box64; a.reordered = f.reordered; a.ntri = f.ntri;
+    static const bool cull_on = !(getenv("SWR_CULL") && atoi(getenv("SWR_CULL")) == 0);
+    a.cull = cull_on ? 1 : 0;
     a.geo = f.geo; a.geo_full = f.geo_full;
     a.tile_count = f.tile_count; a.ranges = f.ranges; a.tg = f.tg;
     a.metal = (f.flags & SWR_FLAG_METAL_RULES) ? 1 : 0;
@@ -1344,21 +1396,15 @@ BinPlan plan_binning(int64_t ntri, int ntiles) {
     if (g > 16 * COLSEG) g = 16 * COLSEG;
     if (g < 1) g = 1;
     p.G = (int)g;
-    p.chunk = (int)((ntri + g - 1) / g);
+    p.chunk = (int)((ntri + g - 1) / g);                      // (informational: the kernels walk the live-group list)
     if (p.chunk < 1) p.chunk = 1;
     return p;
 }
 
 void launch_split_scene(const swr_vertex* v, int64_t nv, const int64_t* idx, int64_t ni, float4* xyz,
-                        float4* rgb, uint32_t* idx32, float4* tri_rgb, hipStream_t s) {
+                        float4* rgb, uint32_t* idx32, hipStream_t s) {
     if (nv <= 0 && ni <= 0) return;
-    hipLaunchKernelGGL(k_split_scene, dim3(2048), dim3(256), 0, s, v, nv, idx, ni, xyz, rgb, idx32, tri_rgb);
-}
-
-void launch_split_attrs(const swr_vertex_attr* attrs, int64_t nv, const uint32_t* idx32, int64_t ni,
-                        float4* tri_nrm, float4* tri_rgb, hipStream_t s) {
-    if (nv <= 0 || ni <= 0) return;
-    hipLaunchKernelGGL(k_split_attrs, dim3(2048), dim3(256), 0, s, attrs, nv, idx32, ni, tri_nrm, tri_rgb);
+    hipLaunchKernelGGL(k_split_scene, dim3(2048), dim3(256), 0, s, v, nv, idx, ni, xyz, rgb, idx32);
 }
 
 void launch_texture_to_float(const uint32_t* bgra, int64_t n, float4* out, hipStream_t s) {
@@ -1377,8 +1423,10 @@ void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)k_fill_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
+        const int64_t groups = (f.ntri + 63) / 64;
+        hipLaunchKernelGGL(k_cull_groups, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a, f.live, f.live_parity);
         hipLaunchKernelGGL(k_setup_hist, dim3(f.plan.G), dim3(BIN_THREADS), f.plan.lds_bytes, s, a, f.bin_matrix,
-                           f.plan.chunk, ntiles);
+                           f.live, f.live_parity, ntiles);
         hipLaunchKernelGGL(k_colscan, dim3((ntiles + 15) / 16), dim3(256), 0, s, f.bin_matrix, f.plan.G, ntiles,
                            f.tile_count);
     } else {
@@ -1400,7 +1448,7 @@ void launch_fill(const DeviceFrame& f, hipStream_t s) {
     if (f.plan.use_lds) {
         hipLaunchKernelGGL(k_fill_lds, dim3(f.plan.G), dim3(BIN_THREADS), f.plan.lds_bytes + 4 * BIN_THREADS, s, f.ranges, f.ntri,
                            f.bin_matrix, f.tile_count, f.tile_start, f.counters, f.host_counters, f.bins,
-                           f.capacity, f.plan.chunk, ntiles,
+                           f.capacity, f.live, f.live_parity, ntiles,
                            f.tg.tiles_x, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
     } else {
         const unsigned blocks = (unsigned)((f.ntri + 255) / 256);
@@ -1419,6 +1467,7 @@ void launch_sort_bins(const DeviceFrame& f, hipStream_t s) {
 void launch_raster(const DeviceFrame& f, hipStream_t s) {
     RasterArgs a;
     a.geo = f.geo; a.geo_full = f.geo_full; a.tri_rgb = f.tri_rgb;
+    a.inv = f.inv; a.reordered = f.reordered;
     a.tri_nrm = f.tri_nrm;
     a.fs.shader = f.material.shader; a.fs.shininess_log2 = f.material.shininess_log2;
     a.fs.light_dir = make_float3(f.material.light_dir[0], f.material.light_dir[1], f.material.light_dir[2]);

@@ -483,3 +483,58 @@ def test_frames_in_flight_pipelining(gpu_ctx, oracle, swr):
         c, d = gpu_ctx.read_color(), gpu_ctx.read_depth()
         rc, rd, _, _ = oracle.render(s.vertices, s.indices, ms[k], 400, 300, DT | oracle.TINV_PER_TRIANGLE)
         assert_same(c, d, rc, rd, f"draw+read {k}")
+
+
+# ---- the sorted triangle stream and the per-band group cull (swr_upload.hip, group_culled) ------------
+def _perspective(rot, tz, near_cut=False):
+    """P * T(0,0,tz) * R_y(rot): w = z_eye (App.swift:176-181 shape).  With near_cut some vertices get w <= 0
+    (behind the eye): the reference does not clip, and neither the oracle nor the cull may special-case them."""
+    c, s_ = np.cos(rot), np.sin(rot)
+    r = np.array([[c, 0, s_, 0], [0, 1, 0, 0], [-s_, 0, c, 0], [0, 0, 0, 1]], dtype=np.float64)
+    t = np.eye(4); t[2, 3] = tz
+    p = np.array([[1, 0, 0, 0], [0, 1, 0, 0], [0, 0, 1, 0], [0, 0, 1, 0.2 if near_cut else 1.0]], dtype=np.float64)
+    return np.ascontiguousarray((p @ t @ r).astype(np.float32).T).reshape(16)
+
+
+@pytest.mark.parametrize("rot,tz,near_cut", [(0.0, 0.0, False), (0.7, 1.5, False), (2.4, 0.6, True), (1.2, -0.4, True)])
+@pytest.mark.parametrize("flags", [DT, 0, MR])
+def test_group_cull_in_bands_under_perspective(swr, oracle, rot, tz, near_cut, flags):
+    """Eight tile-row bands (the 8-GPU layout) of a soup seen through a perspective transform: a band culls the
+    64-primitive groups whose projected box misses it.  Must be invisible in the image, including when vertices
+    are behind the eye, off-screen, or when whole groups are."""
+    s = swr.scenes.random_soup(6000, 320, 512, 0xC011 + int(rot * 10), r_ndc=0.05, margin=1.6)
+    s.vertices[:, 2] = s.vertices[:, 2] * 2.0 - 1.0                       # z in [-1, 1]: depth varies on screen
+    m = _perspective(rot, tz, near_cut)
+    if flags & MR:
+        ref_c, ref_d, _, rc = oracle.render_metal(s.vertices, s.indices, m, 320, 512)
+    else:
+        ref_c, ref_d, _, rc = oracle.render(s.vertices, s.indices, m, 320, 512, flags | oracle.TINV_PER_TRIANGLE)
+    assert rc == 0
+    color = np.full((512, 320, 4), 7, dtype=np.uint8)
+    depth = np.full((512, 320), 7, dtype=np.float32)
+    with swr.Context() as ctx:
+        ctx.scene_upload(s.vertices, s.indices)
+        for k in range(8):
+            r0, r1 = swr.band_rows(512, 8, k)
+            ctx.target_set(320, 512, r0, r1)
+            ctx.draw(m, flags)
+            ctx.read_color(color)
+            ctx.read_depth(depth)
+    assert_same(color, depth, ref_c, ref_d, f"8 bands rot={rot} tz={tz} near_cut={near_cut} flags={flags}")
+
+
+def test_stream_order_is_invisible_with_ties_and_nonfinite_vertices(gpu_ctx, oracle, swr):
+    """Keys carry the ORIGINAL primitive index: exact duplicates (equal depth everywhere) must resolve to the
+    lowest index under the z-test and the highest in painter's order, wherever the Morton sort put them; a
+    non-finite vertex poisons its group's box (never culled) and only its own triangle is skipped."""
+    s = swr.scenes.random_soup(1500, 300, 200, 0x71E5, r_ndc=0.2, margin=1.0)
+    v = np.concatenate([s.vertices, s.vertices[::-1].copy(), s.vertices])     # three copies, one reversed
+    n = s.vertices.shape[0]
+    idx = np.concatenate([s.indices, (n - 1 - s.indices[::-1]) + n, s.indices + 2 * n]).astype(np.int64)
+    v[17 * 3, 0] = np.nan
+    v[n + 40 * 3 + 1, 1] = np.inf
+    for flags in (DT, 0):
+        ref_c, ref_d, st, rc = oracle.render(v, idx, s.transform, 300, 200, flags | oracle.TINV_PER_TRIANGLE)
+        assert rc == 0 and st.triangles_skipped >= 2
+        c, d = gpu_ctx.render(v, idx, s.transform, 300, 200, flags)
+        assert_same(c, d, ref_c, ref_d, f"duplicates flags={flags}")

@@ -173,7 +173,11 @@ DeviceFrame make_frame(swr_context* c, int si, const float m[16], uint32_t flags
     f.plan = plan_binning(f.ntri, tiles_of(c->tg));
     f.bin_matrix = (uint32_t*)sl.bin_matrix.p;
     f.live = (uint32_t*)sl.live.p;
-    f.live_parity = sl.live_parity;
+    // The cull pass pays for itself when this context owns a band of the framebuffer (one GPU of several):
+    // most groups then miss the band.  For the whole framebuffer it is skipped (SWR_CULL=2 forces it, =0 forbids).
+    static const int cull_mode = getenv("SWR_CULL") ? atoi(getenv("SWR_CULL")) : 1;
+    const bool banded = c->tg.row_begin > 0 || c->tg.row_end < c->tg.height;
+    f.live_parity = (cull_mode == 2 || (cull_mode == 1 && banded)) ? sl.live_parity : -1;
     f.bins = (uint32_t*)sl.bins.p;
     f.capacity = c->capacity;
     f.color = (uint8_t*)c->color.p;
@@ -256,7 +260,7 @@ int enqueue_frame(swr_context* c) {
     }
     const bool all = c->timing >= 2;
     if (ev && all) HIP_TRY(c, hipEventRecord(ev[0], sb));
-    if (f.plan.use_lds && f.ntri > 0) sl.live_parity ^= 1;    // k_cull_groups zeroes the other count for the next use
+    if (f.plan.use_lds && f.ntri > 0 && f.live_parity >= 0) sl.live_parity ^= 1;   // k_cull_groups zeroes the other count for the next use
     launch_setup_bin(f, sb);
     if (ev && all) HIP_TRY(c, hipEventRecord(ev[1], sb));
     launch_scan(f, sb);

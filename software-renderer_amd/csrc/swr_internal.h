@@ -92,7 +92,7 @@ struct DeviceFrame {
     uint32_t* bins;                // [capacity] primitive ids grouped by tile
     uint32_t* bin_matrix;          // [G][tiles] per-workgroup tile counts -> prefixes (LDS path)
     uint32_t* live;                // [2 + ceil(ntri/64)] live stream groups of the frame (k_cull_groups)
-    int32_t live_parity;           // which of live[0] / live[1] is this frame's count
+    int32_t live_parity;           // which of live[0] / live[1] is this frame's count; -1: no cull pass, all groups live
     BinPlan plan;
     uint32_t capacity;
     uint8_t* color;

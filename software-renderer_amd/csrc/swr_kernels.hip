@@ -447,10 +447,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_setup_hist(SetupArgs a, uint32_
     for (int e = threadIdx.x; e < ntiles; e += blockDim.x) hist[e] = 0u;
     __syncthreads();
     const int tiles_x = a.tg.tiles_x;
-    const uint32_t nlive = live[parity];
+    // parity < 0: no cull pass ran this frame (the band is the whole framebuffer) — every group is live
+    const uint32_t nlive = parity < 0 ? (uint32_t)((a.ntri + 63) >> 6) : live[parity];
     const uint32_t G = gridDim.x;
     for (uint32_t j = (threadIdx.x >> 6) * G + blockIdx.x; j < nlive; j += G * (BIN_THREADS / 64)) {   // per wave
-        const int64_t p = ((int64_t)live[2 + j] << 6) + (threadIdx.x & 63);
+        const int64_t p = ((int64_t)(parity < 0 ? j : live[2 + j]) << 6) + (threadIdx.x & 63);
         uint2 r = make_uint2(RANGE_NONE_X, 0u);
         if (p < a.ntri) {
             r = setup_triangle(a, p);
@@ -541,10 +542,10 @@ __global__ __launch_bounds__(BIN_THREADS) void k_fill_lds(const uint2* __restric
     const uint32_t* row = M + (size_t)blockIdx.x * (size_t)ntiles;
     for (int e = t; e < ntiles; e += BIN_THREADS) cursor[e] += row[e];
     __syncthreads();
-    const uint32_t nlive = live[parity];
+    const uint32_t nlive = parity < 0 ? (uint32_t)((ntri + 63) >> 6) : live[parity];
     const uint32_t G = gridDim.x;
     for (uint32_t j = (t >> 6) * G + blockIdx.x; j < nlive; j += G * (BIN_THREADS / 64)) {   // same walk as k_setup_hist
-        const int64_t p = ((int64_t)live[2 + j] << 6) + (t & 63);
+        const int64_t p = ((int64_t)(parity < 0 ? j : live[2 + j]) << 6) + (t & 63);
         const uint2 r = p < ntri ? ranges[p] : make_uint2(RANGE_NONE_X, 0u);
         for_each_tile(unpack_box(r), (uint32_t)p, [&](const PixBox& b, uint32_t prim, int tx, int ty) {
             const uint32_t pos = atomicAdd(&cursor[ty * tiles_x + tx], 1u);
@@ -1374,8 +1375,7 @@ void launch_validate_indices(const int64_t* indices, int64_t count, int64_t vert
 static SetupArgs make_setup_args(const DeviceFrame& f) {
     SetupArgs a;
     a.tri_xyz = f.tri_xyz; a.box64 = f.box64; a.reordered = f.reordered; a.ntri = f.ntri;
-    static const bool cull_on = !(getenv("SWR_CULL") && atoi(getenv("SWR_CULL")) == 0);
-    a.cull = cull_on ? 1 : 0;
+    a.cull = f.live_parity >= 0 ? 1 : 0;
     a.geo = f.geo; a.geo_full = f.geo_full;
     a.tile_count = f.tile_count; a.ranges = f.ranges; a.tg = f.tg;
     a.metal = (f.flags & SWR_FLAG_METAL_RULES) ? 1 : 0;
@@ -1424,7 +1424,8 @@ void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
             attr_set = true;
         }
         const int64_t groups = (f.ntri + 63) / 64;
-        hipLaunchKernelGGL(k_cull_groups, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a, f.live, f.live_parity);
+        if (f.live_parity >= 0)
+            hipLaunchKernelGGL(k_cull_groups, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a, f.live, f.live_parity);
         hipLaunchKernelGGL(k_setup_hist, dim3(f.plan.G), dim3(BIN_THREADS), f.plan.lds_bytes, s, a, f.bin_matrix,
                            f.live, f.live_parity, ntiles);
         hipLaunchKernelGGL(k_colscan, dim3((ntiles + 15) / 16), dim3(256), 0, s, f.bin_matrix, f.plan.G, ntiles,

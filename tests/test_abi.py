@@ -105,3 +105,14 @@ def test_host_mirror_compiles_against_the_c_abi(swr):
     for name in ("class Renderer", "class GpuRenderer", "struct RenderPass", "struct Vertex", "struct Pixel",
                  "enum class PrimitiveType", "class Image", "void render(const RenderPass& renderPass)"):
         assert name in hdr
+
+
+def test_abi_version_matches_the_header_and_the_entry_point(swr):
+    """include/swr.h, the built library and __graft_entry__.build() must agree on SWR_ABI_VERSION."""
+    import re
+    hdr = open(os.path.join(ROOT, "include", "swr.h")).read()
+    want = int(re.search(r"#define\s+SWR_ABI_VERSION\s+(\d+)", hdr).group(1))
+    swr.build()
+    assert swr.load_library().swr_abi_version() == want
+    entry = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    assert f"swr_abi_version() == {want}" in entry

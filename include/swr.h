@@ -165,7 +165,10 @@ int swr_render(swr_context* ctx, const swr_render_pass* pass);
  * frame, new transform — without re-uploading; inputs and outputs stay in HBM. ----------- */
 
 /* RenderPass.vertices / .indices (Renderer.swift:195-196); replaces the per-frame
- * makeBuffer / setBytes uploads of GpuRenderer.swift:68-71,93-103.  Validates indices. */
+ * makeBuffer / setBytes uploads of GpuRenderer.swift:68-71,93-103.  Validates indices.
+ * Also builds the device-side triangle stream once (primitives de-indexed and ordered by the Morton code
+ * of their centroid, bounding boxes of 64-primitive groups) — invisible in the image:
+ * painter's order and z-tie order always refer to the caller's index order. */
 int swr_scene_upload(swr_context* ctx, const swr_vertex* vertices, int64_t vertex_count,
                      const int64_t* indices, int64_t index_count);
 

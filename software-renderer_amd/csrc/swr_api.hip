@@ -390,8 +390,10 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     if ((rc = ensure(c, c->idx32, (size_t)index_count * 4))) return rc;
     if ((rc = ensure(c, c->tri_rgb, (size_t)index_count * 16))) return rc;
     const int64_t ntri = index_count / 3;
-    static const bool sort_on = !(getenv("SWR_SORT") && atoi(getenv("SWR_SORT")) == 0);
-    const bool reorder = sort_on && ntri > 1 && ntri < SORT_MAX_TRIS;
+    // SWR_SORT=0: keep index order (the original index still travels in GeomRec.flags);
+    // SWR_SORT=-1: behave as for a scene of 2^24 primitives or more (no reordering, slot == index) — test hook
+    static const int sort_mode = getenv("SWR_SORT") ? atoi(getenv("SWR_SORT")) : 1;
+    const bool reorder = sort_mode == 1 && ntri > 1 && ntri < SORT_MAX_TRIS;
     const size_t sort_bytes = reorder ? stream_sort_temp_bytes(ntri) : 0;
     if ((rc = ensure(c, c->tri_xyz, (size_t)index_count * 16))) return rc;
     if ((rc = ensure(c, c->inv, (size_t)ntri * 4))) return rc;
@@ -429,7 +431,7 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
         b.tri_xyz = (float4*)c->tri_xyz.p; b.tri_rgb = (float4*)c->tri_rgb.p;
         b.inv = (uint32_t*)c->inv.p; b.box64 = (float4*)c->box64.p;
         HIP_TRY(c, launch_build_stream(b, c->stream));
-        c->reordered = ntri > 0 && ntri < SORT_MAX_TRIS;   // original index travels in GeomRec.flags
+        c->reordered = ntri > 0 && ntri < SORT_MAX_TRIS && sort_mode != -1;   // original index travels in GeomRec.flags
     }
     HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->slot[0].tilebuf.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));

@@ -367,7 +367,10 @@ __device__ __forceinline__ void for_each_tile(const PixBox& b, uint32_t p, F&& f
     }
 }
 
-constexpr int BIN_THREADS = 1024;  // workgroup size of k_setup_hist / k_fill_lds (512 measured no better beside raster workgroups)
+#ifndef SWR_BIN_THREADS
+#define SWR_BIN_THREADS 1024
+#endif
+constexpr int BIN_THREADS = SWR_BIN_THREADS;  // workgroup size of k_setup_hist / k_fill_lds (512 measured no better beside raster workgroups)
 
 // ---- binning, LDS path (default): no global atomics ------------------------------------------
 // Can the 64 primitives of stream group `g` be skipped by this band?  True only when the projection of

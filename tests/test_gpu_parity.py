@@ -538,3 +538,42 @@ def test_stream_order_is_invisible_with_ties_and_nonfinite_vertices(gpu_ctx, ora
         assert rc == 0 and st.triangles_skipped >= 2
         c, d = gpu_ctx.render(v, idx, s.transform, 300, 200, flags)
         assert_same(c, d, ref_c, ref_d, f"duplicates flags={flags}")
+
+
+@pytest.mark.parametrize("env", [{"SWR_SORT": "-1"}, {"SWR_SORT": "0", "SWR_CULL": "2"}, {"SWR_CULL": "0"}],
+                         ids=["no-reorder(>=2^24 path)", "index-order+forced-cull", "no-cull"])
+def test_stream_modes_in_a_child_process(env):
+    """The library reads SWR_SORT / SWR_CULL once: exercise the other modes in a child process.  SWR_SORT=-1 is the
+    path scenes of 2^24 primitives or more take (slot == index, nothing in GeomRec.flags); SWR_CULL=2 runs the cull
+    pass on whole-framebuffer targets too (off-screen groups)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r"""
+import sys, numpy as np
+sys.path.insert(0, %r)
+import swr_amd
+from oracle import oracle
+S = swr_amd.scenes
+with swr_amd.Context() as ctx:
+    for flags in (0, 1, 4):
+        s = S.random_soup(5000, 500, 400, 0xABC + flags, r_ndc=0.08, margin=1.7)     # plenty off-screen
+        m = S.app_transform(0.8, scale=1.2)
+        if flags == 4:
+            rc, rd, _, code = oracle.render_metal(s.vertices, s.indices, m, 500, 400)
+        else:
+            rc, rd, _, code = oracle.render(s.vertices, s.indices, m, 500, 400, flags | oracle.TINV_PER_TRIANGLE)
+        c = np.zeros((400, 500, 4), np.uint8); d = np.zeros((400, 500), np.float32)
+        ctx.scene_upload(s.vertices, s.indices)
+        for k in range(3):
+            r0, r1 = swr_amd.band_rows(400, 3, k)
+            ctx.target_set(500, 400, r0, r1); ctx.draw(m, flags); ctx.read_color(c); ctx.read_depth(d)
+        assert code == 0 and np.array_equal(c, rc) and d.tobytes() == rd.tobytes(), ("bands", flags)
+        c, d = ctx.render(s.vertices, s.indices, m, 500, 400, flags)
+        assert np.array_equal(c, rc) and d.tobytes() == rd.tobytes(), ("full", flags)
+print("child ok")
+""" % root
+    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0 and "child ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]

@@ -1124,13 +1124,26 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
                             const float dyp = ((float)(Y0 + yl) + 0.5f) - tb.w;            // (y + .5) - p3.y
                             const float divider = ta.w * ta.x - ta.y * ta.z;               // :143
                             const float n0 = ta.y * dyp, n1 = ta.w * dyp;
+                            // n / divider, correctly rounded, with the divisor's share of the work hoisted out of
+                            // the pixel loop: this is the compiler's own f32 division sequence (rcp, one Newton
+                            // step, quotient, two residual corrections) minus v_div_scale / v_div_fixup, which are
+                            // identities here — GEOM_SMALL triangles have an integer divider with 1 <= |divider| <
+                            // 2^31 and numerators that are 0 or multiples of 1/4 below 2^33, so nothing is scaled,
+                            // denormal, infinite or NaN.  (The wave-cooperative path and the resolve divide plainly.)
+                            const float rc0 = __builtin_amdgcn_rcpf(divider);
+                            const float rcp = __builtin_fmaf(__builtin_fmaf(-divider, rc0, 1.0f), rc0, rc0);
+                            auto div_exact = [&](float n) {
+                                const float q0 = n * rcp;
+                                const float q1 = __builtin_fmaf(__builtin_fmaf(-divider, q0, n), rcp, q0);
+                                return __builtin_fmaf(__builtin_fmaf(-divider, q1, n), rcp, q1);
+                            };
 #pragma unroll
                             for (int q = 0; q < UNIT; q++) {
                                 const float dxp = dxp0 + (float)q;
                                 float w0 = ta.x * dxp + n0;                                // :144
-                                w0 = w0 / divider;                                         // :145
+                                w0 = div_exact(w0);                                        // :145
                                 float w1 = ta.z * dxp + n1;                                // :147
-                                w1 = w1 / divider;                                         // :148
+                                w1 = div_exact(w1);                                        // :148
                                 const float w2 = 1.0f - w0 - w1;                           // :149
                                 const bool inside = 0.0f <= w0 && w0 <= 1.0f && 0.0f <= w1 && w1 <= 1.0f &&
                                                     0.0f <= w2 && w2 <= 1.0f;              // :153

@@ -577,3 +577,14 @@ print("child ok")
     out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True,
                          timeout=300)
     assert out.returncode == 0 and "child ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+
+
+def test_metal_rules_full_size_and_wide_divider_range(gpu_ctx, oracle, swr):
+    """The dense Metal path divides with a hoisted reciprocal + residual corrections (k_raster, METAL): check it
+    against the oracle's plain IEEE division on ~10^8 ROI pixels — BASELINE cfg4 at full size and a soup whose
+    triangles span 3..400 pixels (dividers from a few units to ~10^5)."""
+    s = swr.scenes.cfg4_soup(depth_only=False)
+    check_metal(gpu_ctx, oracle, s, what="cfg4 1M triangles 4K, Metal rules")
+    for seed, r in ((1, 0.004), (2, 0.03), (3, 0.15)):
+        t = swr.scenes.random_soup(30000 if r < 0.1 else 3000, 2048, 1536, 0xD1F + seed, r_ndc=r, margin=1.05)
+        check_metal(gpu_ctx, oracle, t, what=f"metal soup r={r}")

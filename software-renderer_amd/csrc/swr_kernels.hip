@@ -1,6 +1,12 @@
 // swr_kernels.hip — gfx950 (CDNA4, wave64) kernels of the triangle hot path.
 //
+// Input of every frame is the triangle stream built once per scene by swr_upload.hip: primitives in
+// Morton order of their centroid, de-indexed (tri_xyz / tri_rgb / tri_nrm per slot corner), with the
+// bounding box of every 64-slot group.  Bins hold slots; visibility keys hold ORIGINAL indices.
+//
 // One frame (no host round trip; binning runs on its own stream, one frame ahead of the raster):
+//   k_cull_groups 1 lane / group    : (banded targets only) groups whose projected box provably misses
+//                                     the band are dropped; the others form the frame's live list
 //   k_setup_hist  1 lane / triangle : vertex_shader x3, /w, screen map, truncation (or round() under
 //                                     the Metal rules), y-sort, validity via T(); 32-B GeomRec;
 //                                     band-clipped pixel bbox (8 B/triangle); per-workgroup tile
@@ -21,7 +27,9 @@
 //                                     4 pixels (clear fused: HBM sees each pixel exactly once).
 //   k_raster<.., METAL>             : the same frame under the Metal path's rules (SWR_FLAG_METAL_RULES)
 //   k_points / k_points_resolve     : PrimitiveType .vertices;  k_clear_band: .line (reference stub)
-//   k_split_scene, k_validate_indices: once per swr_scene_upload
+//   k_raster<.., EXT>               : + the extended fragment stage at the resolve (normal / uv varyings,
+//                                     Blinn-Phong, bilinear texture; swr_shaders.hip.h)
+//   k_split_scene, k_validate_indices, k_texture_to_float: once per upload
 //
 // Semantics restated from renderer/Renderer.swift (reference file:line cited inline):
 //   visibility without z-test = highest primitive index covering the pixel (painter's order of

@@ -49,7 +49,7 @@ def load_traffic():
     return None
 
 
-def cpu_baseline(scene, budget_s: float = 20.0):
+def cpu_baseline(scene, budget_s: float = 15.0):
     """The oracle (kind 'port': C restatement of Renderer.swift, per-pixel 2x2 inverse kept,
     single thread like the reference) on whole frames of the same workload."""
     from oracle import oracle
@@ -57,7 +57,7 @@ def cpu_baseline(scene, budget_s: float = 20.0):
     times = []
     t_all = time.perf_counter()
     frames = 0
-    while frames < 2 or (time.perf_counter() - t_all < budget_s and frames < 12):
+    while frames < 2 or (time.perf_counter() - t_all < budget_s and frames < 40):   # ~15 s of CPU work
         t0 = time.perf_counter()
         _, _, st, rc = oracle.render_scene(scene)
         assert rc == 0

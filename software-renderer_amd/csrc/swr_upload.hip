@@ -205,7 +205,7 @@ hipError_t launch_build_stream(const StreamBuild& b, hipStream_t s) {
     uint32_t* ids_out = b.scratch + 3 * b.ntri;
     uint32_t* bounds = b.scratch + 4 * b.ntri;
     hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, s, bounds);
-    if (b.nv > 0) hipLaunchKernelGGL(k_scene_bounds, dim3(1024), dim3(256), 0, s, b.xyz, b.nv, bounds);
+    if (b.nv > 0) hipLaunchKernelGGL(k_scene_bounds, dim3(128), dim3(256), 0, s, b.xyz, b.nv, bounds);   // 6 atomics per wave
     hipLaunchKernelGGL(k_morton, dim3(2048), dim3(256), 0, s, b.xyz, b.nv, b.indices, b.ntri, bounds, codes_in, ids_in,
                        b.sort ? 1 : 0);
     const uint32_t* perm = ids_in;

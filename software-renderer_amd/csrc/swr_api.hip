@@ -266,12 +266,15 @@ int enqueue_frame(swr_context* c) {
     launch_scan(f, sb);
     if (ev && all) HIP_TRY(c, hipEventRecord(ev[2], sb));
     launch_fill(f, sb);
-    // Without timing events k_sort_bins runs on the raster stream, right before k_raster: the binning stream is
-    // free one kernel earlier for the next frame (-3 % per frame at 4K, -8 % on a half-frame band).  With events
-    // around k_raster (timing level >= 1, what bench.py uses) the extra kernel ahead of the first event costs more
-    // than it saves (0.137 vs 0.130 ms), so the sort stays on the binning stream.  SWR_SORT_STREAM=0/1 forces either.
+    // Heavy frames without timing events: k_sort_bins runs on the raster stream, right before k_raster, so the
+    // binning stream is free one kernel earlier for the next frame (tools/ab_sort_stream.py, alternating A/B on one
+    // box: cfg4 132 -> 126 us, its half-frame band 86 -> 79 us).  Light frames are bound by the longer of the two
+    // kernel chains and lose (cfg2: 38 -> 43 us), and with events around k_raster (timing level >= 1, what bench.py
+    // uses) the extra kernel ahead of the first event costs more than it saves (0.137 vs 0.130 ms): both keep the
+    // sort on the binning stream.  SWR_SORT_STREAM=0/1 forces either.
     static const int sort_stream_mode = getenv("SWR_SORT_STREAM") ? atoi(getenv("SWR_SORT_STREAM")) : -1;
-    const bool sort_on_raster_stream = sort_stream_mode >= 0 ? sort_stream_mode == 1 : (c->timing == 0 && sb != sr);
+    const bool sort_on_raster_stream = sort_stream_mode >= 0 ? sort_stream_mode == 1
+                                                            : (c->timing == 0 && sb != sr && f.ntri >= 200000);
     if (!sort_on_raster_stream) launch_sort_bins(f, sb);
     if (sb != sr) {
         HIP_TRY(c, hipEventRecord(sl.bin_done, sb));

@@ -51,7 +51,10 @@ struct swr_context {
     Target tg{};
     bool has_target = false;
     DevBuf color, depth;
-    static constexpr int NSLOT = 2;
+#ifndef SWR_NSLOT
+#define SWR_NSLOT 2
+#endif
+    static constexpr int NSLOT = SWR_NSLOT;
     // Per-frame working set, multi-buffered: the binning kernels of frame N+1 run on `bin_stream`
     // while k_raster of frame N runs on `stream` (HBM-bound vs LDS/VALU-bound: they overlap well).
     struct Slot {

@@ -137,10 +137,16 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    def timed(flags, steps, warmup, level=1):
+    # HIP events around k_raster on its own stream, live inside the timed region, on every SAMPLE-th launch: an
+    # event pair on the raster stream is a synchronisation point that costs a pipelined frame about 15 us, so
+    # bracketing every launch would slow the very region it measures (SWR_BENCH_TIMING_SAMPLE=1 does that).
+    SAMPLE = max(1, int(os.environ.get("SWR_BENCH_TIMING_SAMPLE", "8")))
+
+    def timed(flags, steps, warmup, level=1, sample=1):
         for _ in range(warmup):
             ctx.draw(scene.transform, flags)
         sync_all()
+        ctx.timing_sample(sample)
         ctx.timing_enable(level)
         ctx.timing_reset()
         barrier()
@@ -161,7 +167,8 @@ def main():
         return dt, sums, frames
 
     flags = scene.flags
-    dt, sums, frames = timed(flags, args.steps, args.warmup, level=int(os.environ.get("SWR_BENCH_TIMING_LEVEL", "1")))
+    dt, sums, frames = timed(flags, args.steps, args.warmup, level=int(os.environ.get("SWR_BENCH_TIMING_LEVEL", "1")),
+                             sample=SAMPLE)
     ms_per_step = dt / args.steps * 1e3
     mpix = W * H * args.steps / dt / 1e6
 
@@ -176,7 +183,7 @@ def main():
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
         "traffic": (traffic or {}).get("k_raster_bytes_per_launch") if world == 1 else None,
         "algorithmic_bytes_per_launch": band_px * bytes_per_px,
-        "avg_launch_ms": round(raster_ms, 5), "launches_timed": frames,
+        "avg_launch_ms": round(raster_ms, 5), "launches_timed": frames, "timed_every_nth_launch": SAMPLE,
         "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 5),
     }
     # per-stage breakdown from a short separate run with frame pipelining off (stages serialised on
@@ -205,7 +212,7 @@ def main():
 
     if not args.no_extra and world == 1:
         # the same scene with the colour store on (8 B/pixel) — reported beside the headline
-        dt2, sums2, frames2 = timed(S.FLAG_DEPTH_TEST, max(args.steps // 4, 5), 3)
+        dt2, sums2, frames2 = timed(S.FLAG_DEPTH_TEST, max(args.steps // 4, 5), 3, sample=min(SAMPLE, 4))
         steps2 = max(args.steps // 4, 5)
         r2 = sums2["raster_ms"] / max(frames2, 1)
         extra["color_plus_depth"] = {

@@ -205,6 +205,11 @@ int swr_read_depth(swr_context* ctx, float* dst_full_image);
  * the dominant kernel (k_raster) only, 2 = around every stage (each event costs a few us of
  * stream time, so level 2 perturbs the frame it measures). */
 int swr_timing_enable(swr_context* ctx, int level);
+/* Level 1 only: bracket the k_raster of every n-th frame instead of every frame (default 1).  An event pair on
+ * the raster stream is a synchronisation point that costs a pipelined 4K frame about 15 us; sampling keeps the
+ * measurement live inside a timed region without slowing every frame of it.  swr_timing_totals' frame count is
+ * the number of frames actually bracketed. */
+int swr_timing_sample(swr_context* ctx, int every_nth);
 int swr_get_timings(swr_context* ctx, swr_timings* out);          /* the last frame */
 /* Sums over every frame drawn since swr_timing_reset (events are kept in a ring, so a whole
  * timed region of frames is measured without a host sync per frame). */

@@ -20,6 +20,7 @@ ABI_SYMBOLS = [
     "swr_render", "swr_scene_upload", "swr_target_set", "swr_draw", "swr_draw_primitives", "swr_sync", "swr_read_color",
     "swr_read_depth", "swr_timing_enable", "swr_get_timings", "swr_timing_totals", "swr_timing_reset", "swr_pipeline_enable", "swr_tile_rows", "swr_tile_cols",
     "swr_band_rows", "swr_scene_attributes", "swr_material_set", "swr_texture_upload",
+    "swr_timing_sample",
 ]
 
 
@@ -119,6 +120,8 @@ def load_library():
     L.swr_get_timings.argtypes = [vp, ctypes.POINTER(Timings)]
     L.swr_timing_totals.argtypes = [vp, ctypes.POINTER(Timings), ctypes.POINTER(i64)]
     L.swr_timing_reset.argtypes = [vp]
+    L.swr_timing_sample.argtypes = [vp, ctypes.c_int]
+    L.swr_timing_sample.restype = ctypes.c_int
     L.swr_pipeline_enable.argtypes = [vp, ctypes.c_int]
     L.swr_pipeline_enable.restype = ctypes.c_int
     L.swr_band_rows.argtypes = [i64, i32, i32, ctypes.POINTER(i64), ctypes.POINTER(i64)]
@@ -242,6 +245,10 @@ class Context:
         """0/False off, 1 = events around k_raster only, 2/True = around every stage."""
         level = 2 if level is True else (0 if level is False else int(level))
         self._check(self._L.swr_timing_enable(self._h, level))
+
+    def timing_sample(self, every_nth: int):
+        """Level-1 timing brackets only every n-th frame's k_raster."""
+        self._check(self._L.swr_timing_sample(self._h, int(every_nth)))
 
     def timings(self) -> dict:
         t = Timings()

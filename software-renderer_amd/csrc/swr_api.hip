@@ -52,7 +52,7 @@ struct swr_context {
     bool has_target = false;
     DevBuf color, depth;
 #ifndef SWR_NSLOT
-#define SWR_NSLOT 2
+#define SWR_NSLOT 3   // working sets in flight: binning may run up to two frames ahead of the raster (2 -> 3: -3 %)
 #endif
     static constexpr int NSLOT = SWR_NSLOT;
     // Per-frame working set, multi-buffered: the binning kernels of frame N+1 run on `bin_stream`
@@ -83,6 +83,7 @@ struct swr_context {
     // whole timed region of frames can be measured without a host sync per frame
     static constexpr int RING = 64;
     int timing = 0;            // 0 off, 1 = events around k_raster only, 2 = around every stage
+    int timing_every = 1;      // level 1: bracket only every n-th frame's k_raster (swr_timing_sample)
     hipEvent_t ev[RING][5]{};
     int ev_level[RING]{};
     bool ev_ok = false;
@@ -241,7 +242,7 @@ int enqueue_frame(swr_context* c) {
     swr_context::Slot& sl = c->slot[si];
     DeviceFrame f = make_frame(c, si, c->last_m, c->last_flags);
     hipEvent_t* ev = nullptr;
-    if (c->timing) {
+    if (c->timing >= 2 || (c->timing == 1 && (c->frame_no % (uint64_t)c->timing_every) == 0)) {
         if (c->seq - c->harvested >= (uint64_t)swr_context::RING) {   // ring full: drain it
             int rc = sync_streams(c);
             if (rc) return rc;
@@ -269,15 +270,15 @@ int enqueue_frame(swr_context* c) {
     launch_scan(f, sb);
     if (ev && all) HIP_TRY(c, hipEventRecord(ev[2], sb));
     launch_fill(f, sb);
-    // Heavy frames without timing events: k_sort_bins runs on the raster stream, right before k_raster, so the
-    // binning stream is free one kernel earlier for the next frame (tools/ab_sort_stream.py, alternating A/B on one
-    // box: cfg4 132 -> 126 us, its half-frame band 86 -> 79 us).  Light frames are bound by the longer of the two
-    // kernel chains and lose (cfg2: 38 -> 43 us), and with events around k_raster (timing level >= 1, what bench.py
-    // uses) the extra kernel ahead of the first event costs more than it saves (0.137 vs 0.130 ms): both keep the
-    // sort on the binning stream.  SWR_SORT_STREAM=0/1 forces either.
+    // Where k_sort_bins runs.  On the binning stream it is part of the chain that runs ahead of the raster; on
+    // the raster stream (right before k_raster) the binning stream is free one kernel earlier.  Alternating A/B on
+    // one box (tools/ab_sort_stream.py, tools/bt_bands.sh; untimed frames of cfg4, us per frame):
+    //   whole 4K frame (4 080 tiles): 112 vs 122 -> binning stream;  half / quarter / eighth bands: 83 / 59 / 41
+    //   vs 73 / 49 / 40 -> raster stream;  light frames (cfg2, 6 k triangles): 37 vs 43 -> binning stream.
+    // SWR_SORT_STREAM=0/1 forces either.
     static const int sort_stream_mode = getenv("SWR_SORT_STREAM") ? atoi(getenv("SWR_SORT_STREAM")) : -1;
     const bool sort_on_raster_stream = sort_stream_mode >= 0 ? sort_stream_mode == 1
-                                                            : (c->timing == 0 && sb != sr && f.ntri >= 200000);
+                                                            : (sb != sr && f.ntri >= 200000 && tiles_of(c->tg) < 3000);
     if (!sort_on_raster_stream) launch_sort_bins(f, sb);
     if (sb != sr) {
         HIP_TRY(c, hipEventRecord(sl.bin_done, sb));
@@ -618,6 +619,14 @@ int swr_timing_enable(swr_context* c, int enable) {
     int rc = swr_sync(c);
     if (rc) return rc;
     c->timing = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
+    return SWR_OK;
+}
+
+int swr_timing_sample(swr_context* c, int every_nth) {
+    if (!c || every_nth < 1) return SWR_ERR_BAD_ARG;
+    int rc = swr_sync(c);
+    if (rc) return rc;
+    c->timing_every = every_nth;
     return SWR_OK;
 }
 

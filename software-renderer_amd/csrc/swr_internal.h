@@ -55,6 +55,7 @@ enum { CNT_PAIRS = 0, CNT_OVERFLOW = 1, CNT_BAD_INDEX = 2, CNT_WORDS = 8 };
 // Geometry of the LDS binning path (see plan_binning in swr_kernels.hip).
 struct BinPlan {
     bool use_lds;
+    int threads;        // workgroup size of the two binning walks
     int G;              // workgroups = rows of the count matrix
     int chunk;          // primitives per workgroup
     size_t lds_bytes;   // tiles * 4

@@ -375,10 +375,12 @@ __device__ __forceinline__ void for_each_tile(const PixBox& b, uint32_t p, F&& f
     }
 }
 
-#ifndef SWR_BIN_THREADS
-#define SWR_BIN_THREADS 1024
-#endif
-constexpr int BIN_THREADS = SWR_BIN_THREADS;  // workgroup size of k_setup_hist / k_fill_lds (512 measured no better beside raster workgroups)
+// Workgroup size of the two binning walks (template parameter BT of k_setup_hist / k_fill_lds): 256 threads.
+// A 256-thread workgroup (44-52 VGPRs, one wave per SIMD, <= 16 KB of LDS) fits on a CU beside five resident
+// raster workgroups, so the binning of frame N+1 really runs WHILE frame N is rasterised; a 1024-thread one
+// (the former default, SWR_BIN_BT=1024) needs four free wave slots and 208 VGPRs per SIMD at once and only gets
+// onto a CU in the raster's tail (cfg4: 132 -> 112 us per frame, tools/bt_g_sweep.sh).
+constexpr int BIN_THREADS = 1024;  // workgroup size of k_setup_hist / k_fill_lds (512 measured no better beside raster workgroups)
 
 // ---- binning, LDS path (default): no global atomics ------------------------------------------
 // Can the 64 primitives of stream group `g` be skipped by this band?  True only when the projection of
@@ -452,7 +454,8 @@ __global__ __launch_bounds__(256) void k_cull_groups(SetupArgs a, uint32_t* __re
 // groups (neighbours on screen, since the stream is Morton-ordered) land in different workgroups, so a
 // band's few live groups spread over the whole GPU and one workgroup's LDS histogram is not hammered on
 // one tile.  k_setup_hist and k_fill_lds walk the same list with the same mapping.
-__global__ __launch_bounds__(BIN_THREADS) void k_setup_hist(SetupArgs a, uint32_t* __restrict__ M,
+template <int BT>
+__global__ __launch_bounds__(BT) void k_setup_hist(SetupArgs a, uint32_t* __restrict__ M,
                                                      const uint32_t* __restrict__ live, int parity, int ntiles) {
     extern __shared__ uint32_t hist[];
     for (int e = threadIdx.x; e < ntiles; e += blockDim.x) hist[e] = 0u;
@@ -461,7 +464,7 @@ __global__ __launch_bounds__(BIN_THREADS) void k_setup_hist(SetupArgs a, uint32_
     // parity < 0: no cull pass ran this frame (the band is the whole framebuffer) — every group is live
     const uint32_t nlive = parity < 0 ? (uint32_t)((a.ntri + 63) >> 6) : live[parity];
     const uint32_t G = gridDim.x;
-    for (uint32_t j = (threadIdx.x >> 6) * G + blockIdx.x; j < nlive; j += G * (BIN_THREADS / 64)) {   // per wave
+    for (uint32_t j = (threadIdx.x >> 6) * G + blockIdx.x; j < nlive; j += G * (BT / 64)) {   // per wave
         const int64_t p = ((int64_t)(parity < 0 ? j : live[2 + j]) << 6) + (threadIdx.x & 63);
         uint2 r = make_uint2(RANGE_NONE_X, 0u);
         if (p < a.ntri) {
@@ -477,37 +480,46 @@ __global__ __launch_bounds__(BIN_THREADS) void k_setup_hist(SetupArgs a, uint32_
     for (int e = threadIdx.x; e < ntiles; e += blockDim.x) row[e] = hist[e];
 }
 
-// 256 threads = 16 tiles x 16 segments of the workgroup axis; G <= 16 * COLSEG.
+// 256 threads = 16 tiles x 16 segments of the workgroup axis; a segment is ceil(G/16) rows, walked in
+// register blocks of COLSEG rows (sum pass, then prefix pass over the same L2-resident columns).
 constexpr int COLSEG = 32;
+constexpr int MAX_BIN_G = 1024;
 __global__ __launch_bounds__(256) void k_colscan(uint32_t* __restrict__ M, int G, int ntiles,
                                                  uint32_t* __restrict__ tile_count) {
     __shared__ uint32_t seg_sum[16][17];
     const int el = threadIdx.x & 15, seg = threadIdx.x >> 4;
     const int e = blockIdx.x * 16 + el;
-    const int g0 = seg * COLSEG;
-    uint32_t v[COLSEG];
+    const int seglen = (G + 15) / 16;
+    const int g0 = seg * seglen, g1 = min(g0 + seglen, G);
     uint32_t sum = 0;
+    if (e < ntiles)
+        for (int gb = g0; gb < g1; gb += COLSEG) {
+            uint32_t v[COLSEG];
 #pragma unroll
-    for (int k = 0; k < COLSEG; k++) {
-        const int g = g0 + k;
-        v[k] = (e < ntiles && g < G) ? M[(size_t)g * ntiles + e] : 0u;
-    }
+            for (int k = 0; k < COLSEG; k++) v[k] = gb + k < g1 ? M[(size_t)(gb + k) * ntiles + e] : 0u;
 #pragma unroll
-    for (int k = 0; k < COLSEG; k++) sum += v[k];
+            for (int k = 0; k < COLSEG; k++) sum += v[k];
+        }
     seg_sum[el][seg] = sum;
     __syncthreads();
     uint32_t run = 0;
     for (int k = 0; k < seg; k++) run += seg_sum[el][k];
+    if (e < ntiles)
+        for (int gb = g0; gb < g1; gb += COLSEG) {
+            uint32_t v[COLSEG];
 #pragma unroll
-    for (int k = 0; k < COLSEG; k++) {
-        const int g = g0 + k;
-        if (e < ntiles && g < G) M[(size_t)g * ntiles + e] = run;
-        run += v[k];
-    }
+            for (int k = 0; k < COLSEG; k++) v[k] = gb + k < g1 ? M[(size_t)(gb + k) * ntiles + e] : 0u;
+#pragma unroll
+            for (int k = 0; k < COLSEG; k++) {
+                if (gb + k < g1) M[(size_t)(gb + k) * ntiles + e] = run;
+                run += v[k];
+            }
+        }
     if (seg == 15 && e < ntiles) tile_count[e] = run;
 }
 
-__global__ __launch_bounds__(BIN_THREADS) void k_fill_lds(const uint2* __restrict__ ranges, int64_t ntri,
+template <int BT>
+__global__ __launch_bounds__(BT) void k_fill_lds(const uint2* __restrict__ ranges, int64_t ntri,
                                                    const uint32_t* __restrict__ M,
                                                    const uint32_t* __restrict__ tile_count,
                                                    uint32_t* __restrict__ tile_start,
@@ -518,30 +530,30 @@ __global__ __launch_bounds__(BIN_THREADS) void k_fill_lds(const uint2* __restric
                                                    int ntiles, int tiles_x, int tag_class) {
     extern __shared__ uint32_t lds[];
     uint32_t* cursor = lds;             // [ntiles]
-    uint32_t* part = lds + ntiles;      // [BIN_THREADS]
+    uint32_t* part = lds + ntiles;      // [BT]
     const int t = threadIdx.x;
     // Every workgroup scans the per-tile totals itself (16 KB from L2, ~1 us) instead of waiting
     // for a single-workgroup scan kernel; workgroup 0 publishes tile_start and the pair total.
-    for (int e = t; e < ntiles; e += BIN_THREADS) cursor[e] = tile_count[e];
+    for (int e = t; e < ntiles; e += BT) cursor[e] = tile_count[e];
     __syncthreads();
-    const int per = (ntiles + BIN_THREADS - 1) / BIN_THREADS;
+    const int per = (ntiles + BT - 1) / BT;
     const int sb = t * per, se = min(sb + per, ntiles);
     uint32_t sum = 0;
     for (int i = sb; i < se; i++) sum += cursor[i];
     part[t] = sum;
     __syncthreads();
-    for (int off = 1; off < BIN_THREADS; off <<= 1) {
+    for (int off = 1; off < BT; off <<= 1) {
         const uint32_t v = (t >= off) ? part[t - off] : 0u;
         __syncthreads();
         part[t] += v;
         __syncthreads();
     }
-    const uint32_t total = part[BIN_THREADS - 1];
+    const uint32_t total = part[BT - 1];
     uint32_t run = part[t] - sum;
     for (int i = sb; i < se; i++) { const uint32_t c = cursor[i]; cursor[i] = run; run += c; }
     __syncthreads();
     if (blockIdx.x == 0) {
-        for (int e = t; e < ntiles; e += BIN_THREADS) tile_start[e] = cursor[e];
+        for (int e = t; e < ntiles; e += BT) tile_start[e] = cursor[e];
         if (t == 0) {
             tile_start[ntiles] = total;
             counters[CNT_PAIRS] = total;                  // read by k_sort_bins / k_raster
@@ -551,11 +563,11 @@ __global__ __launch_bounds__(BIN_THREADS) void k_fill_lds(const uint2* __restric
     }
     if (total > capacity) return;   // overflow: the host grows the bins and redraws
     const uint32_t* row = M + (size_t)blockIdx.x * (size_t)ntiles;
-    for (int e = t; e < ntiles; e += BIN_THREADS) cursor[e] += row[e];
+    for (int e = t; e < ntiles; e += BT) cursor[e] += row[e];
     __syncthreads();
     const uint32_t nlive = parity < 0 ? (uint32_t)((ntri + 63) >> 6) : live[parity];
     const uint32_t G = gridDim.x;
-    for (uint32_t j = (t >> 6) * G + blockIdx.x; j < nlive; j += G * (BIN_THREADS / 64)) {   // same walk as k_setup_hist
+    for (uint32_t j = (t >> 6) * G + blockIdx.x; j < nlive; j += G * (BT / 64)) {   // same walk as k_setup_hist
         const int64_t p = ((int64_t)(parity < 0 ? j : live[2 + j]) << 6) + (t & 63);
         const uint2 r = p < ntri ? ranges[p] : make_uint2(RANGE_NONE_X, 0u);
         for_each_tile(unpack_box(r), (uint32_t)p, [&](const PixBox& b, uint32_t prim, int tx, int ty) {
@@ -1414,10 +1426,12 @@ BinPlan plan_binning(int64_t ntri, int ntiles) {
     p.lds_bytes = (size_t)ntiles * 4;
     const char* force = getenv("SWR_BIN_MODE");
     p.use_lds = p.lds_bytes <= 144 * 1024 && !(force && force[0] == 'a');   // 'atomic' forces the fallback
-    int64_t g = (ntri + BIN_THREADS - 1) / BIN_THREADS;
+    static const int bt = getenv("SWR_BIN_BT") ? atoi(getenv("SWR_BIN_BT")) : 256;
+    p.threads = bt == BIN_THREADS ? BIN_THREADS : 256;
+    int64_t g = (ntri + p.threads - 1) / p.threads;
     static const int gmax = getenv("SWR_BIN_G") ? atoi(getenv("SWR_BIN_G")) : 256;   // 1 per CU (measured best)
     if (g > gmax) g = gmax;
-    if (g > 16 * COLSEG) g = 16 * COLSEG;
+    if (g > MAX_BIN_G) g = MAX_BIN_G;
     if (g < 1) g = 1;
     p.G = (int)g;
     p.chunk = (int)((ntri + g - 1) / g);                      // (informational: the kernels walk the live-group list)
@@ -1443,15 +1457,21 @@ void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
     if (f.plan.use_lds) {
         static bool attr_set = false;
         if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)k_setup_hist, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_fill_lds, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_setup_hist<BIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_fill_lds<BIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_setup_hist<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            (void)hipFuncSetAttribute((const void*)k_fill_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
         const int64_t groups = (f.ntri + 63) / 64;
         if (f.live_parity >= 0)
             hipLaunchKernelGGL(k_cull_groups, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a, f.live, f.live_parity);
-        hipLaunchKernelGGL(k_setup_hist, dim3(f.plan.G), dim3(BIN_THREADS), f.plan.lds_bytes, s, a, f.bin_matrix,
-                           f.live, f.live_parity, ntiles);
+        if (f.plan.threads == 256)
+            hipLaunchKernelGGL(k_setup_hist<256>, dim3(f.plan.G), dim3(256), f.plan.lds_bytes, s, a, f.bin_matrix,
+                               f.live, f.live_parity, ntiles);
+        else
+            hipLaunchKernelGGL(k_setup_hist<BIN_THREADS>, dim3(f.plan.G), dim3(BIN_THREADS), f.plan.lds_bytes, s, a,
+                               f.bin_matrix, f.live, f.live_parity, ntiles);
         hipLaunchKernelGGL(k_colscan, dim3((ntiles + 15) / 16), dim3(256), 0, s, f.bin_matrix, f.plan.G, ntiles,
                            f.tile_count);
     } else {
@@ -1471,10 +1491,16 @@ void launch_fill(const DeviceFrame& f, hipStream_t s) {
     if (f.ntri <= 0) return;
     const int ntiles = f.tg.tiles_x * f.tg.tiles_y;
     if (f.plan.use_lds) {
-        hipLaunchKernelGGL(k_fill_lds, dim3(f.plan.G), dim3(BIN_THREADS), f.plan.lds_bytes + 4 * BIN_THREADS, s, f.ranges, f.ntri,
-                           f.bin_matrix, f.tile_count, f.tile_start, f.counters, f.host_counters, f.bins,
-                           f.capacity, f.live, f.live_parity, ntiles,
-                           f.tg.tiles_x, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
+        if (f.plan.threads == 256)
+            hipLaunchKernelGGL(k_fill_lds<256>, dim3(f.plan.G), dim3(256), f.plan.lds_bytes + 4 * 256, s, f.ranges, f.ntri,
+                               f.bin_matrix, f.tile_count, f.tile_start, f.counters, f.host_counters, f.bins,
+                               f.capacity, f.live, f.live_parity, ntiles,
+                               f.tg.tiles_x, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
+        else
+            hipLaunchKernelGGL(k_fill_lds<BIN_THREADS>, dim3(f.plan.G), dim3(BIN_THREADS), f.plan.lds_bytes + 4 * BIN_THREADS, s,
+                               f.ranges, f.ntri, f.bin_matrix, f.tile_count, f.tile_start, f.counters, f.host_counters,
+                               f.bins, f.capacity, f.live, f.live_parity, ntiles,
+                               f.tg.tiles_x, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
     } else {
         const unsigned blocks = (unsigned)((f.ntri + 255) / 256);
         hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, s, f.ranges, f.ntri, f.tile_cursor, f.counters,

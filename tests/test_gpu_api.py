@@ -107,3 +107,29 @@ def test_many_context_create_destroy(swr):
         with swr.Context() as ctx:
             c, _ = ctx.render(s.vertices, s.indices, s.transform, 64, 64, 0)
             assert (c[..., 3] == 255).sum() > 0
+
+
+def test_timing_sample_brackets_every_nth_frame(swr, oracle):
+    """swr_timing_sample: level-1 events around k_raster on every n-th frame only; images unaffected."""
+    s = swr.scenes.random_soup(3000, 640, 360, 5, r_ndc=0.05, flags=1)
+    with swr.Context() as ctx:
+        ctx.scene_upload(s.vertices, s.indices)
+        ctx.target_set(640, 360)
+        ctx.timing_sample(8)
+        ctx.timing_enable(1)
+        ctx.timing_reset()
+        for _ in range(64):
+            ctx.draw(s.transform, 1)
+        sums, n = ctx.timing_totals()
+        assert n == 8 and sums["raster_ms"] > 0 and sums["setup_bin_ms"] == 0
+        ctx.timing_sample(1)
+        ctx.timing_reset()
+        for _ in range(10):
+            ctx.draw(s.transform, 1)
+        assert ctx.timing_totals()[1] == 10
+        ctx.timing_enable(0)
+        with pytest.raises(swr.SwrError):
+            ctx.timing_sample(0)
+        c, d = ctx.read_color(), ctx.read_depth()
+    rc, rd, _, _ = oracle.render(s.vertices, s.indices, s.transform, 640, 360, 1)
+    assert np.array_equal(c, rc) and d.tobytes() == rd.tobytes()

@@ -217,7 +217,7 @@ int swr_timing_totals(swr_context* ctx, swr_timings* sum_out, int64_t* frames_ou
 int swr_timing_reset(swr_context* ctx);
 
 /* Frame pipelining (on by default): the binning kernels of the next swr_draw run on a second stream,
- * over a double-buffered working set, while the previous frame is still being rasterised.  Results
+ * over a triple-buffered working set, while the previous frame is still being rasterised.  Results
  * are identical either way; 0 serialises the two stages on one stream (clean per-stage timings). */
 int swr_pipeline_enable(swr_context* ctx, int enable);
 

@@ -857,7 +857,10 @@ template <bool ZTEST, int VAR = 0, bool METAL = false, bool EXT = false>
 __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster(RasterArgs a) {
     static_assert(!METAL || ZTEST, "the Metal rules always z-test");
     constexpr int SUPER = 2;   // dense steps whose owner search is done together
-    constexpr int UNIT = 4;    // consecutive pixels of one span handled by one lane of a dense step
+#ifndef SWR_UNIT
+#define SWR_UNIT 4
+#endif
+    constexpr int UNIT = SWR_UNIT;    // consecutive pixels of one span handled by one lane of a dense step
 #ifndef SWR_ROWS
 #define SWR_ROWS 2
 #endif

@@ -846,6 +846,9 @@ __device__ __forceinline__ float pull_f(int byte_addr, float v) {
 
 // VAR > 0: timing-only ablations selected with SWR_DEBUG_VARIANT (results invalid):
 //   1 = no LDS atomic, 2 = no pulls/maths/atomic, 3 = no dense loop, 4 = no row walk at all
+#ifndef SWR_RASTER_MIN_WAVES_EXT
+#define SWR_RASTER_MIN_WAVES_EXT 4   // the extended fragment stage's resolve (normal, uv, texels) needs > 96 VGPRs
+#endif
 #ifndef SWR_RASTER_MIN_WAVES
 #define SWR_RASTER_MIN_WAVES 5   // waves per SIMD the register allocator must allow (measured: 5 spill-free beats 6)
 #endif
@@ -854,7 +857,7 @@ __device__ __forceinline__ float pull_f(int byte_addr, float v) {
 // barycentric with the inside test, the store is bgra8Unorm.
 // EXT = the extended fragment stage (normal / uv varyings, fragment_shader(vin, uniforms)) at the resolve.
 template <bool ZTEST, int VAR = 0, bool METAL = false, bool EXT = false>
-__global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster(RasterArgs a) {
+__global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SWR_RASTER_MIN_WAVES) void k_raster(RasterArgs a) {
     static_assert(!METAL || ZTEST, "the Metal rules always z-test");
     constexpr int SUPER = 2;   // dense steps whose owner search is done together
 #ifndef SWR_UNIT
@@ -862,9 +865,11 @@ __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) void k_raster
 #endif
     constexpr int UNIT = SWR_UNIT;    // consecutive pixels of one span handled by one lane of a dense step
 #ifndef SWR_ROWS
-#define SWR_ROWS 2
+#define SWR_ROWS 3
 #endif
-    constexpr int ROWS = SWR_ROWS;   // consecutive rows of a triangle pooled into one dealing round (<= 4)
+    // consecutive rows of a triangle pooled into one dealing round (<= 4): 3 (whole frame 112.3 -> 110.1 us); the
+    // extended fragment stage's resolve needs the registers, so its instantiations pool 2 (3 would spill 20-28 B/lane)
+    constexpr int ROWS = EXT ? 2 : SWR_ROWS;
     __shared__ uint32_t next_chunk;           // work-stealing cursor over the chunks of the sorted bin
     __shared__ float4 tabA[RASTER_THREADS];   // per triangle of the batch: t00, t01, t10, t11
     __shared__ float4 tabB[RASTER_THREADS];   //                            za, zb, zc, cf.y

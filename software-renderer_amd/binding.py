@@ -182,6 +182,8 @@ class Context:
         except Exception:
             pass
 
+    _m_src = None
+
     def _check(self, rc: int):
         if rc:
             raise SwrError(rc, (self._L.swr_last_error(self._h) or b"").decode())
@@ -221,8 +223,20 @@ class Context:
         self.width, self.height, self.row_begin, self.row_end = width, height, row_begin, row_end
 
     def draw(self, transform: np.ndarray, flags: int = 0, primitive_type: int = 0):
-        m = np.ascontiguousarray(transform, dtype=np.float32).reshape(16)
-        self._check(self._L.swr_draw_primitives(self._h, m.ctypes.data, flags, primitive_type))
+        # the frame loop calls this thousands of times a second: keep the host side of a draw to one ctypes call
+        # (converting the matrix costs more than the call; the same array object is not converted twice)
+        # (a float32 C-contiguous array is passed by its own buffer, so the pointer of the same array object can be
+        # re-used — in-place updates of that array are seen; anything else is converted on every call)
+        if transform is not self._m_src:
+            if (isinstance(transform, np.ndarray) and transform.dtype == np.float32 and transform.size == 16
+                    and transform.flags.c_contiguous):
+                self._m_src, self._m = transform, transform
+            else:
+                self._m_src, self._m = None, np.ascontiguousarray(transform, dtype=np.float32).reshape(16)
+            self._m_ptr = self._m.ctypes.data
+        rc = self._L.swr_draw_primitives(self._h, self._m_ptr, flags, primitive_type)
+        if rc:
+            self._check(rc)
 
     def sync(self):
         self._check(self._L.swr_sync(self._h))

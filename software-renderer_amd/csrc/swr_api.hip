@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -211,7 +212,31 @@ void harvest(swr_context* c) {
     }
 }
 
+// SWR_HOST_PROFILE=1: wall time of the host side of a frame, split by HIP call group, printed at context destroy.
+struct HostProfile {
+    bool on = getenv("SWR_HOST_PROFILE") && atoi(getenv("SWR_HOST_PROFILE")) == 1;
+    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t frames = 0;
+    std::chrono::steady_clock::time_point last;
+    void begin() { if (on) last = std::chrono::steady_clock::now(); }
+    void lap(int k) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        t[k] += std::chrono::duration<double, std::micro>(now - last).count();
+        last = now;
+    }
+    ~HostProfile() {
+        if (on && frames)
+            fprintf(stderr, "[swr host profile] %llu frames, us/frame: prepare %.2f | wait(slot) %.2f | binning launches %.2f | "
+                            "event record+wait %.2f | raster-stream launches %.2f | record(ras_done) %.2f\n",
+                    (unsigned long long)frames, t[0] / frames, t[1] / frames, t[2] / frames, t[3] / frames, t[4] / frames,
+                    t[5] / frames);
+    }
+};
+static HostProfile g_host_profile;
+
 int enqueue_frame(swr_context* c) {
+    g_host_profile.begin();
     {
         const BinPlan plan = plan_binning(c->ni / 3, tiles_of(c->tg));
         if (plan.use_lds) {
@@ -253,8 +278,10 @@ int enqueue_frame(swr_context* c) {
         c->seq++;
     }
     hipStream_t sb = c->bin_stream, sr = c->stream;
-    // this slot's buffers are free again once the raster of two frames ago has read them
+    g_host_profile.lap(0);
+    // this slot's buffers are free again once the raster of NSLOT frames ago has read them
     if (sl.ras_recorded && sb != sr) HIP_TRY(c, hipStreamWaitEvent(sb, sl.ras_done, 0));
+    g_host_profile.lap(1);
     if (!f.plan.use_lds || f.ntri <= 0) {
         // global-atomic fallback: counters must start at zero.  Empty scene: no binning kernel
         // runs at all, so the tile table (counts, starts, counters) is simply zeroed.
@@ -280,15 +307,20 @@ int enqueue_frame(swr_context* c) {
     const bool sort_on_raster_stream = sort_stream_mode >= 0 ? sort_stream_mode == 1
                                                             : (sb != sr && f.ntri >= 200000 && tiles_of(c->tg) < 3000);
     if (!sort_on_raster_stream) launch_sort_bins(f, sb);
+    g_host_profile.lap(2);
     if (sb != sr) {
         HIP_TRY(c, hipEventRecord(sl.bin_done, sb));
         HIP_TRY(c, hipStreamWaitEvent(sr, sl.bin_done, 0));
     }
+    g_host_profile.lap(3);
     if (sort_on_raster_stream) launch_sort_bins(f, sr);
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], sr));
     launch_raster(f, sr);
     if (ev) HIP_TRY(c, hipEventRecord(ev[4], sr));
+    g_host_profile.lap(4);
     if (sb != sr) { HIP_TRY(c, hipEventRecord(sl.ras_done, sr)); sl.ras_recorded = true; }
+    g_host_profile.lap(5);
+    g_host_profile.frames++;
     HIP_TRY(c, hipGetLastError());
     c->draw_pending = true;   // the pair total lands in h_counters[CNT_PAIRS] (written by the scan)
     return SWR_OK;

@@ -590,3 +590,13 @@ def test_metal_rules_full_size_and_wide_divider_range(gpu_ctx, oracle, swr):
     for seed, r in ((1, 0.004), (2, 0.03), (3, 0.15)):
         t = swr.scenes.random_soup(30000 if r < 0.1 else 3000, 2048, 1536, 0xD1F + seed, r_ndc=r, margin=1.05)
         check_metal(gpu_ctx, oracle, t, what=f"metal soup r={r}")
+
+
+def test_large_scene_4m_triangles(gpu_ctx, oracle, swr):
+    """Four times BASELINE config 4: 4 M triangles, ~5 M (triangle, tile) pairs, ~5*10^7 fragments at 4K, colour +
+    depth — exercises the 32-bit pair / bin arithmetic, the Morton sort and the bins' regrowth at scale."""
+    s = swr.scenes.cfg4_soup(ntri=4_000_000, width=3840, height=2160, r_ndc=0.004, depth_only=False, seed=0x5EED0404)
+    ref_c, ref_d, st, rc = oracle.render(s.vertices, s.indices, s.transform, 3840, 2160, DT | oracle.TINV_PER_TRIANGLE)
+    assert rc == 0 and st.fragments > 4e7
+    c, d = gpu_ctx.render(s.vertices, s.indices, s.transform, 3840, 2160, DT)
+    assert_same(c, d, ref_c, ref_d, "4 M triangles")

@@ -1236,9 +1236,20 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
         float4 q2 = make_float4(0, 0, 0, 0), q3 = q2, ca = q2, cb = q2, cc = q2, na = q2, nb = q2, nc = q2;
         float cfx = 0.0f, cfy = 0.0f;
         MetalTri mt = {};
+        // the four winners' stream slots first, as four independent loads: the per-run chain below is then
+        // record / colours (two parallel gathers) instead of inv -> record -> colours
+        unsigned long long key4[4];
+        uint32_t slot4[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const unsigned long long key = keys[ly * TILE_W + lx + k];
+            key4[k] = keys[ly * TILE_W + lx + k];
+            const uint32_t prim = ZTEST ? (uint32_t)key4[k] : 0xFFFFFFFFu - (uint32_t)key4[k];
+            slot4[k] = prim;
+            if (want_color && a.reordered && key4[k] != KEY_EMPTY) slot4[k] = a.inv[prim];
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long key = key4[k];
             uint32_t c = 0u;               // Pixel(0,0,0,0) (:205)
             float d = INFINITY;            // (:206)
             if (key != KEY_EMPTY && x + k <= X1) {
@@ -1254,7 +1265,7 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                         cached_prim = prim;
                         int4 g0;
                         int vx[3], vy[3];
-                        slot = a.reordered ? a.inv[prim] : prim;
+                        slot = (want_color || !a.reordered) ? slot4[k] : a.inv[prim];   // depth-only: only the rare d == 0 winner
                         load_vertices(a.geo, a.geo_full, slot, g0, q3, vx, vy);
                         if (METAL) {
                             metal_consts(vx, vy, q3.x, q3.y, q3.z, mt);

@@ -167,6 +167,7 @@ def main():
         return dt, sums, frames
 
     flags = scene.flags
+    SAMPLE = max(1, min(SAMPLE, args.steps // 8))     # short runs bracket more (or all) of their launches: >= 8 timed
     dt, sums, frames = timed(flags, args.steps, args.warmup, level=int(os.environ.get("SWR_BENCH_TIMING_LEVEL", "1")),
                              sample=SAMPLE)
     ms_per_step = dt / args.steps * 1e3

@@ -5,7 +5,7 @@ OUT=$R/gpurun_out/band_trace
 rm -rf $OUT && mkdir -p $OUT
 cd $R
 if [ -n "$BT" ]; then
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -w -DSWR_BIN_THREADS=$BT -shared -o software-renderer_amd/lib/libswr_hip.so software-renderer_amd/csrc/swr_kernels.hip software-renderer_amd/csrc/swr_api.hip software-renderer_amd/csrc/swr_upload.hip || exit 1
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fno-fast-math -fno-slp-vectorize -w -DSWR_BIN_THREADS=$BT -shared -o software-renderer_amd/lib/libswr_hip.so software-renderer_amd/csrc/swr_kernels.hip software-renderer_amd/csrc/swr_api.hip software-renderer_amd/csrc/swr_upload.hip || exit 1
 fi
 cd /tmp && export TMPDIR=/tmp
 IFS=';' read -ra PAIRS <<< "${BANDS:-4 2}"      # BANDS="8 4;4 2" = band 4 of 8, then band 2 of 4

@@ -60,8 +60,7 @@ struct swr_context {
     // while k_raster of frame N runs on `stream` (HBM-bound vs LDS/VALU-bound: they overlap well).
     struct Slot {
         DevBuf geo, geo_full, ranges, bins, bin_matrix;
-        DevBuf live;           // [2 counts][live stream-group ids] (k_cull_groups)
-        int live_parity = 0;
+        DevBuf live;           // per binning workgroup: count + surviving stream-group ids (k_setup_hist -> k_fill_lds)
         DevBuf tilebuf;        // [CNT_WORDS counters][tiles tile_count][tiles+1 tile_start][tiles cursor]
         hipEvent_t bin_done = nullptr, ras_done = nullptr;
         bool ras_recorded = false;
@@ -182,7 +181,7 @@ DeviceFrame make_frame(swr_context* c, int si, const float m[16], uint32_t flags
     // most groups then miss the band.  For the whole framebuffer it is skipped (SWR_CULL=2 forces it, =0 forbids).
     static const int cull_mode = getenv("SWR_CULL") ? atoi(getenv("SWR_CULL")) : 1;
     const bool banded = c->tg.row_begin > 0 || c->tg.row_end < c->tg.height;
-    f.live_parity = (cull_mode == 2 || (cull_mode == 1 && banded)) ? sl.live_parity : -1;
+    f.live_parity = (cull_mode == 2 || (cull_mode == 1 && banded)) ? 0 : -1;
     f.bins = (uint32_t*)sl.bins.p;
     f.capacity = c->capacity;
     f.color = (uint8_t*)c->color.p;
@@ -291,7 +290,6 @@ int enqueue_frame(swr_context* c) {
     }
     const bool all = c->timing >= 2;
     if (ev && all) HIP_TRY(c, hipEventRecord(ev[0], sb));
-    if (f.plan.use_lds && f.ntri > 0 && f.live_parity >= 0) sl.live_parity ^= 1;   // k_cull_groups zeroes the other count for the next use
     launch_setup_bin(f, sb);
     if (ev && all) HIP_TRY(c, hipEventRecord(ev[1], sb));
     launch_scan(f, sb);
@@ -450,9 +448,7 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
         if ((rc = ensure(c, sl.geo, (size_t)(index_count / 3) * sizeof(GeomRec)))) return rc;
         if ((rc = ensure(c, sl.geo_full, (size_t)(index_count / 3) * sizeof(GeomFull)))) return rc;
         if ((rc = ensure(c, sl.ranges, (size_t)(index_count / 3) * sizeof(uint2)))) return rc;
-        if ((rc = ensure(c, sl.live, (size_t)(2 + (index_count / 3 + 63) / 64) * 4))) return rc;
-        HIP_TRY(c, hipMemsetAsync(sl.live.p, 0, 8, c->stream));     // both frame counts start at zero
-        sl.live_parity = 0;
+        if ((rc = ensure(c, sl.live, (size_t)((index_count / 3 + 63) / 64 + 2 * 1024 + 2) * 4))) return rc;   // [G <= 1024][1 + per]
         if ((rc = ensure(c, sl.tilebuf, (size_t)(CNT_WORDS + 3 * std::max(1, tiles_of(c->tg)) + 1) * 4))) return rc;
     }
     if (vertex_count)

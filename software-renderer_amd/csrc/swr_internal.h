@@ -61,6 +61,7 @@ struct BinPlan {
     size_t lds_bytes;   // tiles * 4
 };
 BinPlan plan_binning(int64_t ntri, int ntiles);
+int live_groups_per_workgroup(int64_t ntri, int G);
 
 // Everything one frame needs, all device pointers.  colour/depth are band-local: element
 // (x, y) of the full image lives at [(y - row_begin) * width + x].
@@ -92,8 +93,8 @@ struct DeviceFrame {
     uint2* ranges;                 // [ntri] band-clipped pixel bbox (x0|x1<<16, y0|y1<<16, y band-relative)
     uint32_t* bins;                // [capacity] primitive ids grouped by tile
     uint32_t* bin_matrix;          // [G][tiles] per-workgroup tile counts -> prefixes (LDS path)
-    uint32_t* live;                // [2 + ceil(ntri/64)] live stream groups of the frame (k_cull_groups)
-    int32_t live_parity;           // which of live[0] / live[1] is this frame's count; -1: no cull pass, all groups live
+    uint32_t* live;                // [G][1 + ceil(groups/G)] per binning workgroup: count + the stream groups that survived its cull
+    int32_t live_parity;           // >= 0: cull the groups against the band; -1: every group is live
     BinPlan plan;
     uint32_t capacity;
     uint8_t* color;

@@ -5,9 +5,9 @@
 // bounding box of every 64-slot group.  Bins hold slots; visibility keys hold ORIGINAL indices.
 //
 // One frame (no host round trip; binning runs on its own stream, one frame ahead of the raster):
-//   k_cull_groups 1 lane / group    : (banded targets only) groups whose projected box provably misses
-//                                     the band are dropped; the others form the frame's live list
-//   k_setup_hist  1 lane / triangle : vertex_shader x3, /w, screen map, truncation (or round() under
+//   k_setup_hist  1 lane / triangle : first, one lane per owned 64-primitive group: groups whose projected box
+//                                     provably misses the band are dropped (banded targets); then per
+//                                     triangle: vertex_shader x3, /w, screen map, truncation (or round() under
 //                                     the Metal rules), y-sort, validity via T(); 32-B GeomRec;
 //                                     band-clipped pixel bbox (8 B/triangle); per-workgroup tile
 //                                     histogram in LDS -> row of the (workgroup x tile) matrix
@@ -433,39 +433,47 @@ __device__ __forceinline__ bool group_culled(const SetupArgs& a, int64_t g) {
 // M[G][tiles].  k_colscan turns every column into an exclusive prefix over g and emits the
 // per-tile totals; k_scan scans the totals; k_fill_lds seeds its LDS cursors with
 // tile_start[t] + M[g][t] and hands out bin positions with returning LDS atomics.
-// First kernel of a frame: the list of stream groups this band has to look at.  live[0] / live[1] are the
-// counts of this frame and of the slot's next frame (the roles swap every frame, `parity` says which is
-// which): this kernel appends to its own count — zeroed one frame earlier — and zeroes the other one, so no
-// memset is ever enqueued.  live[2..] = group ids, in no particular order (the image does not depend on it).
-__global__ __launch_bounds__(256) void k_cull_groups(SetupArgs a, uint32_t* __restrict__ live, int parity) {
-    const int64_t groups = (a.ntri + 63) >> 6;
-    const int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (g == 0) live[1 - parity] = 0u;
-    const bool keep = g < groups && !(a.cull && group_culled(a, g));
-    const unsigned long long mask = __ballot(keep);
-    const int lane = threadIdx.x & 63;
-    uint32_t base = 0u;
-    if (lane == 0 && mask) base = atomicAdd(&live[parity], (uint32_t)__popcll(mask));
-    base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-    if (keep) live[2 + base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)g;
-}
-
-// Live group j of the frame goes to wave (j / G) % 16 of workgroup j % G, then round-robin: neighbouring
-// groups (neighbours on screen, since the stream is Morton-ordered) land in different workgroups, so a
-// band's few live groups spread over the whole GPU and one workgroup's LDS histogram is not hammered on
-// one tile.  k_setup_hist and k_fill_lds walk the same list with the same mapping.
+// Which stream groups (64 primitives, one wave's worth) does this band have to look at?  Workgroup w owns the
+// groups w, w + G, w + 2G, ... — neighbouring groups (neighbours on screen, since the stream is Morton-ordered) go
+// to different workgroups, so a band's few surviving groups spread over the whole GPU and one workgroup's LDS
+// histogram is not hammered on one tile.  Phase 1: one lane per owned group projects the group's box
+// (group_culled) and the survivors are compacted into an LDS list, which is also published to `live`
+// ([G][1 + per]: count, group ids) for k_fill_lds to walk the same groups in the same order.  Phase 2: one wave
+// per surviving group.  (The cull used to be a kernel of its own; a thin band's frame is bound by the host's
+// launch rate, so it moved in here.)
 template <int BT>
 __global__ __launch_bounds__(BT) void k_setup_hist(SetupArgs a, uint32_t* __restrict__ M,
-                                                     const uint32_t* __restrict__ live, int parity, int ntiles) {
-    extern __shared__ uint32_t hist[];
+                                                     uint32_t* __restrict__ live, int per, int ntiles) {
+    extern __shared__ uint32_t hist[];               // [ntiles] histogram, [per] surviving groups, [1] their count
+    uint32_t* mylist = hist + ntiles;                // (all dynamic: the kernel may ask for the whole 160 KB)
+    uint32_t& nlive_s = mylist[per];
+    if (threadIdx.x == 0) nlive_s = 0u;
     for (int e = threadIdx.x; e < ntiles; e += blockDim.x) hist[e] = 0u;
     __syncthreads();
+    {
+        const int64_t groups = (a.ntri + 63) >> 6;
+        const int lane = threadIdx.x & 63;
+        for (int i0 = threadIdx.x & ~63; i0 < per; i0 += BT) {                 // wave-uniform trip count
+            const int i = i0 + lane;
+            const int64_t g = (int64_t)i * gridDim.x + blockIdx.x;
+            const bool keep = i < per && g < groups && !(a.cull && group_culled(a, g));
+            const unsigned long long mask = __ballot(keep);
+            uint32_t base = 0u;
+            if (lane == 0 && mask) base = atomicAdd(&nlive_s, (uint32_t)__popcll(mask));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (keep) mylist[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)g;
+        }
+    }
+    __syncthreads();
+    const uint32_t nlive = nlive_s;
+    {
+        uint32_t* out = live + (size_t)blockIdx.x * (size_t)(per + 1);
+        if (threadIdx.x == 0) out[0] = nlive;
+        for (uint32_t i = threadIdx.x; i < nlive; i += BT) out[1 + i] = mylist[i];
+    }
     const int tiles_x = a.tg.tiles_x;
-    // parity < 0: no cull pass ran this frame (the band is the whole framebuffer) — every group is live
-    const uint32_t nlive = parity < 0 ? (uint32_t)((a.ntri + 63) >> 6) : live[parity];
-    const uint32_t G = gridDim.x;
-    for (uint32_t j = (threadIdx.x >> 6) * G + blockIdx.x; j < nlive; j += G * (BT / 64)) {   // per wave
-        const int64_t p = ((int64_t)(parity < 0 ? j : live[2 + j]) << 6) + (threadIdx.x & 63);
+    for (uint32_t j = threadIdx.x >> 6; j < nlive; j += BT / 64) {   // per wave
+        const int64_t p = ((int64_t)mylist[j] << 6) + (threadIdx.x & 63);
         uint2 r = make_uint2(RANGE_NONE_X, 0u);
         if (p < a.ntri) {
             r = setup_triangle(a, p);
@@ -526,7 +534,7 @@ __global__ __launch_bounds__(BT) void k_fill_lds(const uint2* __restrict__ range
                                                    uint32_t* __restrict__ counters,
                                                    uint32_t* __restrict__ host_counters,
                                                    uint32_t* __restrict__ bins, uint32_t capacity,
-                                                   const uint32_t* __restrict__ live, int parity,
+                                                   const uint32_t* __restrict__ live, int gper,
                                                    int ntiles, int tiles_x, int tag_class) {
     extern __shared__ uint32_t lds[];
     uint32_t* cursor = lds;             // [ntiles]
@@ -565,10 +573,10 @@ __global__ __launch_bounds__(BT) void k_fill_lds(const uint2* __restrict__ range
     const uint32_t* row = M + (size_t)blockIdx.x * (size_t)ntiles;
     for (int e = t; e < ntiles; e += BT) cursor[e] += row[e];
     __syncthreads();
-    const uint32_t nlive = parity < 0 ? (uint32_t)((ntri + 63) >> 6) : live[parity];
-    const uint32_t G = gridDim.x;
-    for (uint32_t j = (t >> 6) * G + blockIdx.x; j < nlive; j += G * (BT / 64)) {   // same walk as k_setup_hist
-        const int64_t p = ((int64_t)(parity < 0 ? j : live[2 + j]) << 6) + (t & 63);
+    const uint32_t* mylist = live + (size_t)blockIdx.x * (size_t)(gper + 1);   // published by k_setup_hist
+    const uint32_t nlive = mylist[0];
+    for (uint32_t j = t >> 6; j < nlive; j += BT / 64) {   // same groups, same order as k_setup_hist
+        const int64_t p = ((int64_t)mylist[1 + j] << 6) + (t & 63);
         const uint2 r = p < ntri ? ranges[p] : make_uint2(RANGE_NONE_X, 0u);
         for_each_tile(unpack_box(r), (uint32_t)p, [&](const PixBox& b, uint32_t prim, int tx, int ty) {
             const uint32_t pos = atomicAdd(&cursor[ty * tiles_x + tx], 1u);
@@ -1439,12 +1447,18 @@ static SetupArgs make_setup_args(const DeviceFrame& f) {
     return a;
 }
 
+// Stream groups owned by one binning workgroup (k_setup_hist / k_fill_lds): ceil(groups / G).
+int live_groups_per_workgroup(int64_t ntri, int G) {
+    const int64_t groups = (ntri + 63) / 64;
+    return (int)((groups + G - 1) / (G > 0 ? G : 1));
+}
+
 // LDS binning geometry: G workgroups of BIN_THREADS threads, each owning `chunk` consecutive primitives.
 BinPlan plan_binning(int64_t ntri, int ntiles) {
     BinPlan p{};
     p.lds_bytes = (size_t)ntiles * 4;
     const char* force = getenv("SWR_BIN_MODE");
-    p.use_lds = p.lds_bytes <= 144 * 1024 && !(force && force[0] == 'a');   // 'atomic' forces the fallback
+    p.use_lds = p.lds_bytes <= 136 * 1024 && !(force && force[0] == 'a');   // 'atomic' forces the fallback (LDS also holds a workgroup's group list)
     static const int bt = getenv("SWR_BIN_BT") ? atoi(getenv("SWR_BIN_BT")) : 256;
     p.threads = bt == BIN_THREADS ? BIN_THREADS : 256;
     int64_t g = (ntri + p.threads - 1) / p.threads;
@@ -1453,8 +1467,10 @@ BinPlan plan_binning(int64_t ntri, int ntiles) {
     if (g > MAX_BIN_G) g = MAX_BIN_G;
     if (g < 1) g = 1;
     p.G = (int)g;
-    p.chunk = (int)((ntri + g - 1) / g);                      // (informational: the kernels walk the live-group list)
+    p.chunk = (int)((ntri + g - 1) / g);                      // (informational: the kernels walk their own group lists)
     if (p.chunk < 1) p.chunk = 1;
+    // the workgroup's list of surviving stream groups shares the LDS with its tile histogram
+    if (p.use_lds && p.lds_bytes + (size_t)(live_groups_per_workgroup(ntri, p.G) + 1) * 4 > 150 * 1024) p.use_lds = false;
     return p;
 }
 
@@ -1482,15 +1498,13 @@ void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
             (void)hipFuncSetAttribute((const void*)k_fill_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             attr_set = true;
         }
-        const int64_t groups = (f.ntri + 63) / 64;
-        if (f.live_parity >= 0)
-            hipLaunchKernelGGL(k_cull_groups, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, a, f.live, f.live_parity);
+        const int per = live_groups_per_workgroup(f.ntri, f.plan.G);
+        const size_t lds = f.plan.lds_bytes + (size_t)(per + 1) * 4;
         if (f.plan.threads == 256)
-            hipLaunchKernelGGL(k_setup_hist<256>, dim3(f.plan.G), dim3(256), f.plan.lds_bytes, s, a, f.bin_matrix,
-                               f.live, f.live_parity, ntiles);
+            hipLaunchKernelGGL(k_setup_hist<256>, dim3(f.plan.G), dim3(256), lds, s, a, f.bin_matrix, f.live, per, ntiles);
         else
-            hipLaunchKernelGGL(k_setup_hist<BIN_THREADS>, dim3(f.plan.G), dim3(BIN_THREADS), f.plan.lds_bytes, s, a,
-                               f.bin_matrix, f.live, f.live_parity, ntiles);
+            hipLaunchKernelGGL(k_setup_hist<BIN_THREADS>, dim3(f.plan.G), dim3(BIN_THREADS), lds, s, a, f.bin_matrix,
+                               f.live, per, ntiles);
         hipLaunchKernelGGL(k_colscan, dim3((ntiles + 15) / 16), dim3(256), 0, s, f.bin_matrix, f.plan.G, ntiles,
                            f.tile_count);
     } else {
@@ -1513,12 +1527,12 @@ void launch_fill(const DeviceFrame& f, hipStream_t s) {
         if (f.plan.threads == 256)
             hipLaunchKernelGGL(k_fill_lds<256>, dim3(f.plan.G), dim3(256), f.plan.lds_bytes + 4 * 256, s, f.ranges, f.ntri,
                                f.bin_matrix, f.tile_count, f.tile_start, f.counters, f.host_counters, f.bins,
-                               f.capacity, f.live, f.live_parity, ntiles,
+                               f.capacity, f.live, live_groups_per_workgroup(f.ntri, f.plan.G), ntiles,
                                f.tg.tiles_x, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
         else
             hipLaunchKernelGGL(k_fill_lds<BIN_THREADS>, dim3(f.plan.G), dim3(BIN_THREADS), f.plan.lds_bytes + 4 * BIN_THREADS, s,
                                f.ranges, f.ntri, f.bin_matrix, f.tile_count, f.tile_start, f.counters, f.host_counters,
-                               f.bins, f.capacity, f.live, f.live_parity, ntiles,
+                               f.bins, f.capacity, f.live, live_groups_per_workgroup(f.ntri, f.plan.G), ntiles,
                                f.tg.tiles_x, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
     } else {
         const unsigned blocks = (unsigned)((f.ntri + 255) / 256);

@@ -177,11 +177,10 @@ DeviceFrame make_frame(swr_context* c, int si, const float m[16], uint32_t flags
     f.plan = plan_binning(f.ntri, tiles_of(c->tg));
     f.bin_matrix = (uint32_t*)sl.bin_matrix.p;
     f.live = (uint32_t*)sl.live.p;
-    // The cull pass pays for itself when this context owns a band of the framebuffer (one GPU of several):
-    // most groups then miss the band.  For the whole framebuffer it is skipped (SWR_CULL=2 forces it, =0 forbids).
+    // Groups of the stream whose projected box misses this context's band (or the framebuffer) are skipped by
+    // k_setup_hist; the test costs one lane-pass per workgroup, so it is always on (SWR_CULL=0 switches it off).
     static const int cull_mode = getenv("SWR_CULL") ? atoi(getenv("SWR_CULL")) : 1;
-    const bool banded = c->tg.row_begin > 0 || c->tg.row_end < c->tg.height;
-    f.live_parity = (cull_mode == 2 || (cull_mode == 1 && banded)) ? 0 : -1;
+    f.live_parity = cull_mode != 0 ? 0 : -1;
     f.bins = (uint32_t*)sl.bins.p;
     f.capacity = c->capacity;
     f.color = (uint8_t*)c->color.p;

@@ -6,7 +6,7 @@
 //
 // One frame (no host round trip; binning runs on its own stream, one frame ahead of the raster):
 //   k_setup_hist  1 lane / triangle : first, one lane per owned 64-primitive group: groups whose projected box
-//                                     provably misses the band are dropped (banded targets); then per
+//                                     provably misses the band / the framebuffer are dropped; then per
 //                                     triangle: vertex_shader x3, /w, screen map, truncation (or round() under
 //                                     the Metal rules), y-sort, validity via T(); 32-B GeomRec;
 //                                     band-clipped pixel bbox (8 B/triangle); per-workgroup tile

@@ -6,9 +6,18 @@
  * every intermediate rounded to float).  All "file:line" notes refer to
  * /root/reference/renderer/Renderer.swift unless another file is named.
  *
- * Deviation (documented in DESIGN.md §2.4): a triangle with a non-finite screen coordinate,
- * a screen coordinate whose magnitude is >= 2^30, or det == 0 is skipped.  The reference
- * would trap (Int(NaN), UInt8(NaN)) or divide by zero there.
+ * Deviation (documented in DESIGN.md §2.4): a triangle with a non-finite screen coordinate or
+ * a screen coordinate whose magnitude is >= 2^30 is skipped.  The reference would trap there
+ * (SIMD2<Int>(SIMD2<Float>) of a NaN / out-of-range value, :251,:271).
+ *
+ * det == 0 (vertices collinear after truncation) is NOT skipped: nothing traps in the reference.
+ * T() (:95-100) divides by zero -> +-inf / NaN entries, the weights and the interpolated colour
+ * become +-inf / NaN, simd_clamp (:119-122) = min(max(v,0),1) with fmax/fmin NaN handling maps
+ * NaN -> 0, +inf -> 1, -inf -> 0, and UInt8() gets a finite value.  So in painter's mode the
+ * degenerate span is written (mostly as (0,0,0,255)); with the z-test restored a NaN depth fails
+ * '<' (:258) and only a -inf depth can pass.  What Apple's closed simd `inverse` returns for a
+ * singular matrix is unknowable here (PARITY UNPINNED); this file uses adjugate / determinant in
+ * IEEE arithmetic like everywhere else.
  */
 #include "swr_oracle.h"
 
@@ -282,13 +291,7 @@ int swro_render(uint8_t* color, float* depth, int64_t W, int64_t H,
             if (!(fabsf(t.sx[k]) < COORD_LIMIT) || !(fabsf(t.sy[k]) < COORD_LIMIT)) { ok = 0; }
             else { t.ix[k] = (int64_t)t.sx[k]; t.iy[k] = (int64_t)t.sy[k]; }   /* :251 truncation */
         }
-        if (ok) {
-            float cfx = (float)t.ix[2] + 0.5f, cfy = (float)t.iy[2] + 0.5f;
-            float m00 = ((float)t.ix[0] + 0.5f) - cfx, m10 = ((float)t.iy[0] + 0.5f) - cfy;
-            float m01 = ((float)t.ix[1] + 0.5f) - cfx, m11 = ((float)t.iy[1] + 0.5f) - cfy;
-            float det = m00 * m11 - m01 * m10;
-            if (!(det != 0.0f) || !isfinite(det)) ok = 0;
-        }
+        /* det == 0 is drawn like any other triangle: see the note at the top of this file */
         if (!ok) { f.st.triangles_skipped++; continue; }
         f.st.triangles_drawn++;
         draw_triangle(&f, &t);                                    /* :228 */

@@ -40,7 +40,7 @@ typedef struct swro_stats {
     int64_t fragments;        /* setPixel calls that passed the bounds check */
     int64_t fragments_written;/* ... that also passed the z-test (== fragments when off) */
     int64_t triangles_drawn;
-    int64_t triangles_skipped;/* non-finite / out-of-range / det == 0 (documented deviation) */
+    int64_t triangles_skipped;/* non-finite / out-of-range screen coordinate (documented deviation) */
 } swro_stats;
 
 /* Renderer.render(renderPass:) restricted to rows [row_begin,row_end) of the W x H images.

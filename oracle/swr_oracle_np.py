@@ -149,9 +149,7 @@ def render(vertices, indices, transform, width, height, depth_test=False, no_col
             col0 = ((F(a[0]) + F(0.5)) - cf[0], (F(a[1]) + F(0.5)) - cf[1])   # af - cf
             col1 = ((F(b[0]) + F(0.5)) - cf[0], (F(b[1]) + F(0.5)) - cf[1])   # bf - cf
             det = col0[0] * col1[1] - col1[0] * col0[1]
-            if not (det != 0 and np.isfinite(det)):
-                skipped += 1
-                continue
+            # det == 0 is not skipped: the divisions give +-inf / NaN, the clamp of :119-122 maps them to 0 / 1
             if inv_rcp:
                 rdet = F(1.0) / det
                 T = ((col1[1] * rdet, -col1[0] * rdet), (-col0[1] * rdet, col0[0] * rdet))

@@ -274,9 +274,14 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
 #pragma unroll
         for (int k = 0; k < 3; k++) { ix[k] = (int)sx[k]; iy[k] = (int)sy[k]; }  // :251 truncation
     }
-    float t00, t01, t10, t11;
-    const float det = tinv_of(ix[0], iy[0], ix[1], iy[1], ix[2], iy[2], t00, t01, t10, t11);
-    ok = ok && (det != 0.0f) && (fabsf(det) < INFINITY);
+    // det == 0 (vertices collinear after truncation) is drawn like any other triangle under the CPU rules: T()
+    // (:95-100) then holds +-inf / NaN, the clamp of :119-122 maps such colours to 0 / 1 and a NaN depth fails
+    // the '<' of :258 — nothing traps in the reference.  (Under the Metal rules det is the shader's `divider`.)
+    if (a.metal) {
+        float t00, t01, t10, t11;
+        const float det = tinv_of(ix[0], iy[0], ix[1], iy[1], ix[2], iy[2], t00, t01, t10, t11);
+        ok = ok && (det != 0.0f) && (fabsf(det) < INFINITY);
+    }
 
     // :271 stable 3-element insertion sort on FLOAT y
     int o0 = 0, o1 = 1, o2 = 2;

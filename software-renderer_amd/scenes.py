@@ -253,23 +253,72 @@ def _disc_offsets(seed: int, n: int, offset: int, tries: int = 8) -> np.ndarray:
     return pick
 
 
+def uniform01_at(seed: int, index: np.ndarray) -> np.ndarray:
+    """uniform01 at arbitrary draw numbers (SplitMix64 is counter-based): float32 like uniform01(seed, n)[index]."""
+    with np.errstate(over="ignore"):
+        i = np.asarray(index, dtype=np.uint64) + np.uint64(1)
+        z = np.uint64(seed) + i * _GAMMA
+        z = (z ^ (z >> np.uint64(30))) * _M1
+        z = (z ^ (z >> np.uint64(27))) * _M2
+        z = z ^ (z >> np.uint64(31))
+    return ((z >> np.uint64(40)).astype(np.float32)) * np.float32(1.0 / 16777216.0)
+
+
+def screen_truncated(xyz: np.ndarray, width: int, height: int):
+    """Truncated screen coordinates of NDC positions under the identity transform, with the pipeline's own
+    float32 operations (Renderer.swift:166-168, :251): returns int64 (sx, sy)."""
+    f = np.float32
+    sx = ((xyz[..., 0] * f(0.5) + f(0.5)) * f(width)).astype(np.int64)
+    sy = ((xyz[..., 1] * f(-0.5) + f(0.5)) * f(height)).astype(np.int64)
+    return sx, sy
+
+
+def degenerate_mask(xyz: np.ndarray, width: int, height: int) -> np.ndarray:
+    """[ntri] bool: the three truncated screen vertices are collinear (det of T() == 0, Renderer.swift:95-100)."""
+    sx, sy = screen_truncated(xyz, width, height)
+    det = (sx[:, 0] - sx[:, 2]) * (sy[:, 1] - sy[:, 2]) - (sx[:, 1] - sx[:, 2]) * (sy[:, 0] - sy[:, 2])
+    return det == 0
+
+
+CFG4_REDRAW_ROUNDS = 12   # a triangle is degenerate with p ~ 1.7 %: 12 independent redraws leave none at 1 M
+
+
 def cfg4_soup(ntri: int = 1_000_000, width: int = 3840, height: int = 2160,
               r_ndc: float = 0.008, depth_only: bool = True, seed: int = 0x5EED0004) -> Scene:
     """Independent random triangles (3 unshared vertices each): centre uniform in
     [-0.98,0.98]^2, vertex offsets uniform in a disc of radius r_ndc, z uniform [0.05,0.95],
-    colours uniform, identity transform (w = 1), z-test ON."""
+    colours uniform, identity transform (w = 1), z-test ON.  Triangles whose
+    truncated screen coordinates are degenerate (det = 0) are regenerated, as §8(d) specifies: redraw round t
+    takes all 62 random numbers of triangle i from the stream seeded seed + t * 2^24 at draws 62 i .. 62 i + 61."""
     centre = uniform01(seed, 2 * ntri, 0).reshape(ntri, 2) * np.float32(1.96) - np.float32(0.98)
     off = _disc_offsets(seed, 3 * ntri, 2 * ntri).reshape(ntri, 3, 2) * np.float32(r_ndc)
     base = 2 * ntri + 2 * 3 * ntri * 8
     z = uniform01(seed, 3 * ntri, base).reshape(ntri, 3) * np.float32(0.9) + np.float32(0.05)
-    rgb = uniform01(seed, 9 * ntri, base + 3 * ntri).reshape(3 * ntri, 3)
+    rgb = uniform01(seed, 9 * ntri, base + 3 * ntri).reshape(ntri, 3, 3)
     xyz = np.empty((ntri, 3, 3), dtype=np.float32)
     xyz[:, :, 0:2] = centre[:, None, :] + off
     xyz[:, :, 2] = z
+    redrawn = 0
+    bad = np.nonzero(degenerate_mask(xyz, width, height))[0]
+    for t in range(1, CFG4_REDRAW_ROUNDS + 1):
+        if bad.size == 0:
+            break
+        redrawn += int(bad.size)
+        u = uniform01_at(seed + t * (1 << 24), bad[:, None].astype(np.uint64) * np.uint64(62) + np.arange(62, dtype=np.uint64))
+        c = u[:, 0:2] * np.float32(1.96) - np.float32(0.98)
+        cand = (u[:, 2:50].reshape(-1, 3, 8, 2)) * np.float32(2.0) - np.float32(1.0)      # 8 disc candidates per vertex
+        inside = (cand[..., 0] * cand[..., 0] + cand[..., 1] * cand[..., 1]) <= np.float32(1.0)
+        first = np.argmax(inside, axis=2)
+        pick = np.take_along_axis(cand, first[:, :, None, None], axis=2)[:, :, 0, :]
+        pick[~inside.any(axis=2)] = 0.0
+        xyz[bad, :, 0:2] = c[:, None, :] + pick * np.float32(r_ndc)
+        xyz[bad, :, 2] = u[:, 50:53] * np.float32(0.9) + np.float32(0.05)
+        rgb[bad] = u[:, 53:62].reshape(-1, 3, 3)
+        bad = bad[degenerate_mask(xyz[bad], width, height)]
     flags = FLAG_DEPTH_TEST | (FLAG_NO_COLOR if depth_only else 0)
-    return Scene("cfg4_soup", width, height, pack_vertices(xyz.reshape(-1, 3), rgb),
+    return Scene("cfg4_soup", width, height, pack_vertices(xyz.reshape(-1, 3), rgb.reshape(-1, 3)),
                  np.arange(3 * ntri, dtype=np.int64), identity(), flags,
-                 {"r_ndc": r_ndc, "seed": seed})
+                 {"r_ndc": r_ndc, "seed": seed, "degenerate_redrawn": redrawn, "degenerate_left": int(bad.size)})
 
 
 def cfg3_phong(**kw) -> Scene:
@@ -341,3 +390,48 @@ def random_soup(ntri: int, width: int, height: int, seed: int, r_ndc: float = 0.
         idx = (splitmix64(seed ^ 0xABCDEF, 3 * ntri) % np.uint64(3 * ntri)).astype(np.int64)
     return Scene(f"soup_{ntri}_{seed:x}", width, height, pack_vertices(xyz.reshape(-1, 3), rgb),
                  idx, identity(), flags, {})
+
+
+def pixel_to_ndc(px, py, width: int, height: int):
+    """NDC coordinates whose screen position is (px, py) under the identity transform (exact for the dyadic
+    sizes the tests use: x = px / W * 2 - 1, y = 1 - py / H * 2)."""
+    return (np.float32(px) / np.float32(width) * np.float32(2.0) - np.float32(1.0),
+            np.float32(1.0) - np.float32(py) / np.float32(height) * np.float32(2.0))
+
+
+def degenerate_mix(width: int = 256, height: int = 128, seed: int = 0x5EED0300, flags: int = 0,
+                   only_degenerate: bool = False) -> Scene:
+    """Triangles whose TRUNCATED vertices are collinear (det of T() == 0, Renderer.swift:95-100) between ordinary
+    ones: horizontal, vertical and diagonal runs, single points, with zero / negative / mixed-sign z and colours.
+    The reference draws their scanline span with +-inf / NaN weights (clamped at :119-122; a NaN depth fails :258)."""
+    soup = random_soup(120, width, height, seed, r_ndc=0.2, margin=1.05)
+    lines = [  # pixel-space vertex triples (a, b, c): all collinear after truncation
+        ((10.5, 20.5), (30.5, 20.5), (20.5, 20.5)),      # horizontal, c in the middle (SURVEY-style KAT in tests)
+        ((40.25, 30.75), (40.75, 60.25), (40.5, 45.5)),  # vertical
+        ((60.5, 10.5), (80.5, 30.5), (70.5, 20.5)),      # diagonal
+        ((90.5, 90.5), (90.6, 90.4), (90.7, 90.9)),      # a single pixel
+        ((100.5, 50.5), (120.5, 50.5), (140.5, 50.5)),   # horizontal, c at the end
+        ((150.5, 70.5), (130.5, 60.5), (170.5, 80.5)),   # slope 1/2
+        ((200.5, 100.5), (200.5, 100.5), (220.5, 110.5)),  # two coincident vertices
+        ((-5.5, 64.5), (300.5, 64.5), (100.5, 64.5)),    # leaves the screen on both sides
+    ]
+    zs = [(0.5, 0.5, 0.5), (-0.5, -0.25, 0.75), (0.0, 0.0, 0.0), (-1.0, -1.0, 2.0), (0.25, -0.5, 0.5)]
+    cols = [(1.0, 0.5, 0.25), (0.0, 0.0, 0.0), (-0.5, 2.0, 0.5), (1.0, 0.0, 0.0)]
+    xyz, rgb = [], []
+    k = 0
+    for rep in range(5):
+        for tri in lines:
+            z = zs[(k + rep) % len(zs)]
+            for j, (px, py) in enumerate(tri):
+                nx, ny = pixel_to_ndc(px + rep * 3, py + rep, width, height)
+                xyz.append((nx, ny, z[j]))
+                rgb.append(cols[(k + j) % len(cols)])
+            k += 1
+    dv = pack_vertices(np.asarray(xyz, np.float32), np.asarray(rgb, np.float32))
+    if only_degenerate:
+        return Scene("degenerate_only", width, height, dv, np.arange(dv.shape[0], dtype=np.int64), identity(), flags, {})
+    nv0 = soup.vertices.shape[0]
+    # interleave: ordinary triangles before, between and after the degenerate ones (painter's order matters)
+    half = (soup.indices.size // 6) * 3
+    idx = np.concatenate([soup.indices[:half], nv0 + np.arange(dv.shape[0], dtype=np.int64), soup.indices[half:]])
+    return Scene("degenerate_mix", width, height, np.concatenate([soup.vertices, dv]), idx, identity(), flags, {})

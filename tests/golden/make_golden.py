@@ -81,6 +81,8 @@ def main():
     emit("soup500_depth_only", S.random_soup(500, 200, 120, 0x5EED0102, r_ndc=0.1, margin=1.1), 3)
     emit("soup64_big", S.random_soup(24, 320, 200, 0x5EED0103, r_ndc=1.1, margin=0.7), 1)
     emit("torus_app_transform", S.cfg2_teapot_scale(320, 180, time=1.0, nu=16, nv=24), 1)
+    emit("degenerate_painter", S.degenerate_mix(), 0)
+    emit("degenerate_ztest", S.degenerate_mix(), 1)
     emit("cfg4_mini", S.cfg4_soup(ntri=4000, width=240, height=136, r_ndc=0.06, depth_only=False, seed=0x5EED0004), 1)
 
 

@@ -153,12 +153,32 @@ def test_degenerate_and_nonfinite_triangles_skipped(gpu_ctx, oracle, swr):
     v[12, 1] = np.inf
     v[15, 0] = 3.0e38                        # finite but beyond the 2^30 coordinate limit
     st = check(gpu_ctx, oracle, s)
-    assert st.triangles_skipped >= 5
+    assert st.triangles_skipped == 3         # only the non-finite / out-of-range ones: det == 0 is drawn (Renderer.swift:95-100)
     m = swr.scenes.identity()
     m[15] = 0.0; m[11] = 1.0                 # w = z: vertices with z = 0 divide by zero
     s.vertices[30:33, 2] = 0.0
     s.transform = m
     check(gpu_ctx, oracle, s)
+
+
+@pytest.mark.parametrize("flags", [0, DT, DT | NC])
+def test_degenerate_triangles_are_drawn_like_the_reference(gpu_ctx, oracle, swr, flags):
+    """det == 0 after truncation: T() holds +-inf / NaN (Renderer.swift:95-100), nothing traps; painter's mode writes
+    the span with clamped colours (:119-122), a NaN depth fails the '<' of :258.  (was skipped.)"""
+    s = swr.scenes.degenerate_mix(flags=flags)
+    st = check(gpu_ctx, oracle, s)
+    assert st.triangles_skipped == 0
+    # hand-derived: a = (10,20), b = (30,20), c = (20,20): one row, span [R, L] = [10, 20], every weight NaN -> (0,0,0,255)
+    S = swr.scenes
+    xyz = [(*S.pixel_to_ndc(px, py, 256, 128), 0.5) for px, py in ((10.5, 20.5), (30.5, 20.5), (20.5, 20.5))]
+    v = S.pack_vertices(np.asarray(xyz, np.float32), np.tile(np.float32([1, .5, .25]), (3, 1)))
+    c, d = gpu_ctx.render(v, np.arange(3), S.identity(), 256, 128, flags & ~NC)
+    if flags & DT:
+        assert not c.any() and np.isposinf(d).all()
+    else:
+        ys, xs = np.nonzero(c[..., 3])
+        assert set(ys) == {20} and (xs.min(), xs.max(), xs.size) == (10, 20, 11)
+        assert (c[20, 10:21] == (0, 0, 0, 255)).all() and np.isposinf(d).all()
 
 
 def test_nan_colour_and_out_of_range_colour(gpu_ctx, oracle, swr):

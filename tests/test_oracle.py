@@ -40,6 +40,34 @@ def test_kat_c2_gouraud(oracle, swr):
     assert np.array_equal(c, c2)                         # both inverse variants agree on this frame
 
 
+def test_kat_degenerate_triangle_is_drawn(oracle, swr):
+    """det == 0 (vertices collinear after truncation): nothing traps in the reference — T() (:95-100) holds +-inf / NaN,
+    simd_clamp (:119-122) maps a NaN colour to 0.  Hand-derived: a=(10,20) b=(30,20) c=(20,20) in pixels, one row;
+    left chain at y == S2.y returns S2.x = 20, right chain has dy == 0 -> S0.x = 10, swapped -> span [10, 20];
+    m = [[-10, 10], [0, 0]], det = -0, every weight is NaN -> 11 pixels of (0,0,0,255); with the z-test a NaN depth
+    fails '<' (:258) and nothing is written."""
+    S = swr.scenes
+    xyz = [(*S.pixel_to_ndc(px, py, 256, 128), 0.5) for px, py in ((10.5, 20.5), (30.5, 20.5), (20.5, 20.5))]
+    v = S.pack_vertices(np.asarray(xyz, np.float32), np.tile(np.float32([1, .5, .25]), (3, 1)))
+    c, d, st, rc = oracle.render(v, np.arange(3), S.identity(), 256, 128, 0)
+    assert rc == 0 and st.fragments == 11 and st.triangles_skipped == 0
+    ys, xs = np.nonzero(c[..., 3])
+    assert set(ys) == {20} and (xs.min(), xs.max()) == (10, 20)
+    assert (c[20, 10:21] == (0, 0, 0, 255)).all() and np.isposinf(d).all()
+    c, d, st, rc = oracle.render(v, np.arange(3), S.identity(), 256, 128, 1)
+    assert not c.any() and np.isposinf(d).all() and st.fragments == 11 and st.fragments_written == 0
+    for fl in (0, 1):
+        s = S.degenerate_mix(flags=fl)
+        c, d, st, rc = oracle.render_scene(s)
+        c2, d2, sk = onp.render(s.vertices, s.indices, s.transform, s.width, s.height, depth_test=bool(fl))
+        assert sk == st.triangles_skipped == 0 and np.array_equal(c, c2) and d.tobytes() == d2.tobytes()
+        s = S.degenerate_mix(flags=fl, only_degenerate=True)
+        c, d, st, _ = oracle.render_scene(s)
+        c3, d3, _, _ = oracle.render_scene(s, oracle.INV_RCP)        # adj * (1/det): the same infinities and NaNs
+        assert st.fragments > 400 and np.array_equal(c, c3) and d.tobytes() == d3.tobytes()
+        assert np.isposinf(d).all()                                  # a degenerate triangle never passes the z-test
+
+
 def test_interpolate_unit(oracle):
     """Renderer.interpolate (:467-494): segment pick, truncating division, guards."""
     tri = [(10, 0), (0, 10), (20, 20)]
@@ -191,10 +219,10 @@ def test_error_codes(oracle, swr):
 def test_skip_rule(oracle, swr):
     s = swr.scenes.random_soup(10, 64, 64, 3, r_ndc=0.3)
     s.vertices[0, 0] = np.nan
-    s.vertices[3:6, 0:2] = 0.125
+    s.vertices[3:6, 0:2] = 0.125                         # zero area: det == 0 is NOT skipped (one pixel, NaN weights)
     s.vertices[6, 1] = 4e38
     _, _, st, rc = oracle.render_scene(s)
-    assert rc == 0 and st.triangles_skipped == 3 and st.triangles_drawn == 7
+    assert rc == 0 and st.triangles_skipped == 2 and st.triangles_drawn == 8
 
 
 # ---- scene generators --------------------------------------------------------------------------
@@ -207,6 +235,10 @@ def test_scene_generators_are_deterministic(swr):
     assert np.abs(xy).max() <= 0.98 + 0.008 + 1e-6
     z = a.vertices[:, 2]
     assert z.min() >= 0.05 and z.max() <= 0.95
+    # degenerate triangles (det == 0 after truncation) are regenerated
+    big = S.cfg4_soup(ntri=30000)
+    assert big.meta["degenerate_redrawn"] > 100 and big.meta["degenerate_left"] == 0
+    assert not S.degenerate_mask(big.vertices[:, 0:3].reshape(-1, 3, 3), big.width, big.height).any()
     assert S.cfg2_teapot_scale().triangles == 6320
     assert S.cfg3_bunny_scale().triangles == 69451
     assert S.cfg5_sponza_scale().triangles == 262144

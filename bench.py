@@ -1,20 +1,33 @@
 #!/usr/bin/env python3
 """bench.py — the BASELINE.json metric on MI355X: Mpixels/s (and frames/s) at 4K on the
-1M-triangle synthetic soup (config 4: 3840x2160, z-test, depth-only), one process per GPU.
+1M-triangle synthetic soup (config 4: 3840x2160, z-test, depth-only).
 
     python bench.py [--gpus N --steps K --warmup W]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 A "step" is one frame of the hot path (clear + vertex transform + setup + binning + tile raster
-+ framebuffer write) over the resident scene; inputs and the framebuffer stay in HBM.  With
-N > 1 the framebuffer is split into N tile-row bands; every rank holds the whole
-scene and renders its band; there is no collective on the data path (bands are disjoint), only
-the timing barrier.  The total work is fixed as N grows => "scaling": "strong".
++ framebuffer write) over the resident scene; inputs and the framebuffer stay in HBM.
 
-Prints ONE JSON line on rank 0.  `roofline` is for the dominant kernel (k_raster): algorithmic
-framebuffer bytes of the band / its mean HIP-event duration over the timed region, against the
-8 TB/s HBM peak.  `cpu_baseline` (rank 0, N = 1 only) times the CPU oracle — the C restatement
-of the reference's Renderer.swift loop — on whole frames of the same workload.
+N GPUs: the framebuffer is split into N tile-row bands; every GPU holds the whole scene and
+renders its band; no collective on the data path (bands are disjoint).  Two ways to get there:
+  * under a launcher (WORLD_SIZE = N): one process per GPU, torch.distributed only for the timing barrier and the
+    MAX over ranks (nccl = RCCL);
+  * WITHOUT a launcher: ONE process, ONE multi-device context (swr_config.device_count = N): the library fans every
+    call out to N per-device sub-contexts on their own host threads.  Needs N visible GPUs, otherwise the run
+    exits non-zero (SWR_BENCH_ALLOW_SHARED=1 lets bands share GPUs as a labelled rehearsal — not a result).
+The total work is fixed as N grows => "scaling": "strong".
+
+Prints ONE JSON line on rank 0.
+  value / ms_per_step   untimed region (no HIP event on any stream), frames pipelined
+  latency_ms            one frame alone, swr_draw -> swr_sync
+  roofline              dominant kernel k_raster from a SEPARATE sampled pass (two HIP events around every n-th
+                        launch, on the raster stream): algorithmic framebuffer bytes of the band / mean duration
+                        vs the 8 TB/s HBM peak; .valu = VALU wave-instructions per launch (rocprofv3 SQ counters,
+                        profiles/) against the chip's issue peak — the resource the kernel is actually bound by
+  extra.host_visible    the same frames with every band copied to ONE page-locked host image (swr_present:
+                        hipMemcpyAsync per band, colour/depth on two copy streams, double-buffered framebuffer)
+  extra.swr_render_ms   the full drop-in call (upload 120 MB + draw + gather, host pointers in, pixels out)
+  cpu_baseline          (rank 0, N = 1 only) the CPU oracle — the C restatement of Renderer.swift's loop
 """
 import argparse
 import json
@@ -30,6 +43,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 HBM_COPY_CEILING_GBS = 6290.0  # measured float4-copy ceiling (same guide)
+# VALU issue peak: 256 CUs x 4 SIMDs, one wave64 VALU instruction per 2 cycles per SIMD, 2.4 GHz (same guide)
+VALU_PEAK_WAVE_INSTS_PER_S = 256 * 4 * 2.4e9 / 2
 
 
 def shard_rows(swr, height: int, world: int, rank: int):
@@ -37,9 +52,8 @@ def shard_rows(swr, height: int, world: int, rank: int):
     return swr.band_rows(height, world, rank)
 
 
-def load_traffic():
-    """HBM bytes per k_raster launch from the committed rocprofv3 PMC passes (profiles/), or None."""
-    p = os.path.join(ROOT, "profiles", "traffic.json")
+def load_profile_json(name):
+    p = os.path.join(ROOT, "profiles", name)
     if os.path.exists(p):
         try:
             with open(p) as f:
@@ -82,20 +96,32 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--color", action="store_true", help="headline = colour+depth instead of depth-only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-extra", action="store_true", help="skip the secondary colour+depth measurement")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary measurements")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and args.gpus != world:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks", file=sys.stderr)
+        sys.exit(2)
+
+    import swr_amd
+    if local_rank == 0:
+        swr_amd.build()          # no-op when the in-tree .so is current
+    ndev = swr_amd.device_count()
+    if ndev <= 0:
+        print("bench.py: no HIP device (the library has no CPU fallback)", file=sys.stderr)
+        sys.exit(2)
+
     dist = None
     torch = None
     device = local_rank
     rehearsal = False
+    in_process = 1          # bands driven by this process's context
     if world > 1:
         import torch
         import torch.distributed as dist
-        ndev = torch.cuda.device_count()
         if ndev >= world or os.environ.get("SWR_BENCH_BACKEND", "") == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
@@ -104,134 +130,218 @@ def main():
             # same code path, ranks share devices, gloo carries the barrier / MAX.  Not a result.
             rehearsal = True
             device = local_rank % max(ndev, 1)
-            torch.cuda.set_device(device)
             dist.init_process_group("gloo")
-    else:
-        try:
-            import torch
-        except Exception:
-            torch = None
-
-    import swr_amd
-    if local_rank == 0:
-        swr_amd.build()          # no-op when the in-tree .so is current
-    if dist is not None:
         dist.barrier()
+    elif args.gpus > 1:
+        # no launcher: one process, one multi-device context
+        in_process = args.gpus
+        device = 0
+        if ndev < args.gpus:
+            if os.environ.get("SWR_BENCH_ALLOW_SHARED", "") != "1":
+                print(f"bench.py: --gpus {args.gpus} but only {ndev} HIP device(s) visible; refusing to report a "
+                      f"{args.gpus}-GPU number (SWR_BENCH_ALLOW_SHARED=1 rehearses with bands sharing GPUs)", file=sys.stderr)
+                sys.exit(3)
+            rehearsal = True
+    n_gpus = world if world > 1 else in_process
     S = swr_amd.scenes
 
-    scene = S.cfg4_soup(ntri=args.triangles, width=args.width, height=args.height,
-                        depth_only=not args.color)
+    scene = S.cfg4_soup(ntri=args.triangles, width=args.width, height=args.height, depth_only=not args.color)
     W, H = scene.width, scene.height
-    r0, r1 = shard_rows(swr_amd, H, world, rank)
+    r0, r1 = shard_rows(swr_amd, H, world, rank) if world > 1 else (0, H)
 
-    ctx = swr_amd.Context(device if world > 1 else -1)
+    ctx = swr_amd.Context(device if (world > 1 or in_process > 1) else -1, device_count=in_process if in_process > 1 else 0)
     ctx.scene_upload(scene.vertices, scene.indices)
     ctx.target_set(W, H, r0, r1)
-
-    def sync_all():
-        ctx.sync()
-        if torch is not None and torch.cuda.is_available():
-            torch.cuda.synchronize()
+    bands = ctx.bands()
+    largest_band_px = W * max(b - a for _, a, b in bands)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    # HIP events around k_raster on its own stream, live inside the timed region, on every SAMPLE-th launch: an
-    # event pair on the raster stream is a synchronisation point that costs a pipelined frame about 15 us, so
-    # bracketing every launch would slow the very region it measures (SWR_BENCH_TIMING_SAMPLE=1 does that).
-    SAMPLE = max(1, int(os.environ.get("SWR_BENCH_TIMING_SAMPLE", "8")))
+    def max_over_ranks(x):
+        if dist is None:
+            return x
+        tt = torch.tensor([x], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
 
-    def timed(flags, steps, warmup, level=1, sample=1):
+    def run(flags, steps, warmup, level=0, sample=1, present=None):
+        """W untimed frames, then exactly `steps` timed frames between barrier + sync on both sides.  level 0: no HIP
+        event anywhere.  present = (color, depth) host images: every frame is also copied to the host (async)."""
         for _ in range(warmup):
             ctx.draw(scene.transform, flags)
-        sync_all()
-        ctx.timing_sample(sample)
+            if present:
+                ctx.present(*present)
+        ctx.present_wait() if present else ctx.sync()      # also grows the bins if the first frame overflowed them
+        if level:
+            ctx.timing_sample(sample)
         ctx.timing_enable(level)
         ctx.timing_reset()
         barrier()
-        sync_all()
+        ctx.sync()
+        if torch is not None and not rehearsal:
+            torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(steps):
             ctx.draw(scene.transform, flags)
-        sync_all()
+            if present:
+                ctx.present(*present)
+        # a frame whose (triangle,tile) pair list overflowed the bins would raster nothing and time as "fast":
+        # sync / present_wait check every frame's pair total and raise (SWR_ERR_FRAME_DROPPED) or redraw
+        ctx.present_wait() if present else ctx.sync()
+        if torch is not None and not rehearsal:
+            torch.cuda.synchronize()
         barrier()
         t1 = time.perf_counter()
-        sums, frames = ctx.timing_totals()
+        sums, frames = ctx.timing_totals() if level else ({}, 0)
         ctx.timing_enable(0)
-        dt = t1 - t0
-        if dist is not None:
-            tt = torch.tensor([dt], dtype=torch.float64, device="cpu" if rehearsal else "cuda")
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            dt = float(tt.item())
-        return dt, sums, frames
+        return max_over_ranks(t1 - t0), sums, frames
 
     flags = scene.flags
-    SAMPLE = max(1, min(SAMPLE, args.steps // 8))     # short runs bracket more (or all) of their launches: >= 8 timed
-    dt, sums, frames = timed(flags, args.steps, args.warmup, level=int(os.environ.get("SWR_BENCH_TIMING_LEVEL", "1")),
-                             sample=SAMPLE)
+    bytes_per_px = 4 if (flags & S.FLAG_NO_COLOR) else 8
+
+    # ---- pass 1: the headline, measured before anything is instrumented -------------------------------------------
+    dt, _, _ = run(flags, args.steps, args.warmup, level=0)
     ms_per_step = dt / args.steps * 1e3
     mpix = W * H * args.steps / dt / 1e6
 
-    # roofline of the dominant kernel on this rank's band
-    bytes_per_px = 4 if (flags & S.FLAG_NO_COLOR) else 8
-    band_px = W * (r1 - r0)
+    # one frame alone: enqueue -> host sees it finished (no other frame in flight)
+    lat = []
+    for _ in range(12):
+        ctx.sync()
+        t0 = time.perf_counter()
+        ctx.draw(scene.transform, flags)
+        ctx.sync()
+        lat.append(time.perf_counter() - t0)
+    latency_ms = max_over_ranks(float(np.median(lat[2:]))) * 1e3
+
+    # ---- pass 2: k_raster's launch duration, sampled (an event pair on the raster stream costs a pipelined frame
+    # ~15 us, so only every n-th launch is bracketed and this pass never feeds `value`) ---------------------------------
+    SAMPLE = max(1, int(os.environ.get("SWR_BENCH_TIMING_SAMPLE", "8")))
+    roof_steps = max(args.steps, 64)
+    SAMPLE = max(1, min(SAMPLE, roof_steps // 8))
+    dt_s, sums, frames = run(flags, roof_steps, 4, level=1, sample=SAMPLE)
     raster_ms = sums["raster_ms"] / max(frames, 1)
-    achieved = band_px * bytes_per_px / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else 0.0
-    traffic = load_traffic()
+    achieved = largest_band_px * bytes_per_px / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else 0.0
+    traffic = load_profile_json("traffic.json") or {}
+    valu = load_profile_json("valu.json") or {}
     roofline = {
         "bound": "hbm", "kernel": "k_raster<ztest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-        "traffic": (traffic or {}).get("k_raster_bytes_per_launch") if world == 1 else None,
-        "algorithmic_bytes_per_launch": band_px * bytes_per_px,
+        "traffic": traffic.get("k_raster_bytes_per_launch") if n_gpus == 1 else None,
+        "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of tools/profile.sh on this workload; static, not re-measured in this run)",
+        "algorithmic_bytes_per_launch": largest_band_px * bytes_per_px,
         "avg_launch_ms": round(raster_ms, 5), "launches_timed": frames, "timed_every_nth_launch": SAMPLE,
+        "ms_per_step_while_sampling": round(dt_s / roof_steps * 1e3, 4),
         "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 5),
     }
-    # per-stage breakdown from a short separate run with frame pipelining off (stages serialised on
-    # one stream) and events around every stage — those events cost stream time, and under
-    # pipelining the stages of two frames overlap, so this stays out of the timed region above
-    ctx.pipeline_enable(False)
-    dt_iso, sums_all, frames_all = timed(flags, max(args.steps // 4, 5), 2, level=2)
-    kernels = {k: round(v / max(frames_all, 1), 5) for k, v in sums_all.items() if k.endswith("_ms")}
-    iso_steps = max(args.steps // 4, 5)
-    _, sums_iso, frames_iso = timed(flags, iso_steps, 2, level=1)
-    ctx.pipeline_enable(True)
-    t_last = ctx.timings()
-    raster_iso_ms = sums_iso["raster_ms"] / max(frames_iso, 1)
-    roofline["isolated"] = {
-        "note": "same kernel with frame pipelining off (nothing else on the GPU)",
-        "avg_launch_ms": round(raster_iso_ms, 5),
-        "achieved": round(band_px * bytes_per_px / (raster_iso_ms * 1e-3) / 1e9, 2) if raster_iso_ms > 0 else None,
-        "frac": round(band_px * bytes_per_px / (raster_iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if raster_iso_ms > 0 else None,
-    }
+    if n_gpus == 1 and valu.get("k_raster_valu_wave_insts_per_launch") and raster_ms > 0:
+        insts = float(valu["k_raster_valu_wave_insts_per_launch"])
+        roofline["valu"] = {
+            "insts": insts, "source": valu.get("source", "profiles/valu.json"),
+            "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS_PER_S,
+            "frac": round(insts / (raster_ms * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S, 4),
+            "note": "the kernel is VALU-issue / latency bound, not HBM bound: this is the fraction of the binding resource"}
 
-    extra = {"frames_per_s": round(args.steps / dt, 2), "kernel_ms_avg": kernels,
-             "kernel_ms_avg_note": "stages serialised (pipelining off); the timed region overlaps binning of frame N+1 with the raster of frame N",
-             "tile_pairs": t_last["tile_pairs"], "tiles": t_last["tiles"], "band_rows": [r0, r1],
-             "tile": list(swr_amd.tile_shape()),
-             "compulsory_bytes_per_frame": band_px * bytes_per_px + 32 * scene.vertices.shape[0] + 8 * scene.indices.size}
+    extra = {"frames_per_s": round(args.steps / dt, 2), "band_rows": [r0, r1], "tile": list(swr_amd.tile_shape()),
+             "bands": [{"device": d, "rows": [a, b]} for d, a, b in bands],
+             "bin_overflow_checked": True,
+             "compulsory_bytes_per_frame": W * (r1 - r0) * bytes_per_px + 32 * scene.vertices.shape[0] + 8 * scene.indices.size,
+             "scene": {"degenerate_redrawn": scene.meta.get("degenerate_redrawn"), "degenerate_left": scene.meta.get("degenerate_left")}}
 
-    if not args.no_extra and world == 1:
-        # the same scene with the colour store on (8 B/pixel) — reported beside the headline
-        dt2, sums2, frames2 = timed(S.FLAG_DEPTH_TEST, max(args.steps // 4, 5), 3, sample=min(SAMPLE, 4))
-        steps2 = max(args.steps // 4, 5)
-        r2 = sums2["raster_ms"] / max(frames2, 1)
-        extra["color_plus_depth"] = {
-            "Mpixels_per_s": round(W * H * steps2 / dt2 / 1e6, 2), "ms_per_step": round(dt2 / steps2 * 1e3, 4),
-            "raster_ms": round(r2, 5), "roofline_frac": round(band_px * 8 / (r2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if r2 > 0 else None}
+    if not args.no_extra:
+        # per-stage breakdown with frame pipelining off (stages serialised on one stream, events around every stage)
+        ctx.pipeline_enable(False)
+        iso_steps = max(args.steps // 4, 5)
+        _, sums_all, frames_all = run(flags, iso_steps, 2, level=2)
+        extra["kernel_ms_avg"] = {k: round(v / max(frames_all, 1), 5) for k, v in sums_all.items() if k.endswith("_ms")}
+        extra["kernel_ms_avg_note"] = "stages serialised (pipelining off); the timed region overlaps binning of frame N+1 with the raster of frame N"
+        _, sums_iso, frames_iso = run(flags, iso_steps, 2, level=1)
+        ctx.pipeline_enable(True)
+        raster_iso_ms = sums_iso["raster_ms"] / max(frames_iso, 1)
+        roofline["isolated"] = {
+            "note": "same kernel with frame pipelining off (nothing else on the GPU)",
+            "avg_launch_ms": round(raster_iso_ms, 5),
+            "achieved": round(largest_band_px * bytes_per_px / (raster_iso_ms * 1e-3) / 1e9, 2) if raster_iso_ms > 0 else None,
+            "frac": round(largest_band_px * bytes_per_px / (raster_iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if raster_iso_ms > 0 else None,
+        }
+        t_last = ctx.timings()
+        extra["tile_pairs"], extra["tiles"] = t_last["tile_pairs"], t_last["tiles"]
+
+        if n_gpus == 1:
+            # the same scene with the colour store on (8 B/pixel) — reported beside the headline
+            steps2 = max(args.steps // 4, 5)
+            dt2, _, _ = run(S.FLAG_DEPTH_TEST, steps2, 3, level=0)
+            _, sums2, frames2 = run(S.FLAG_DEPTH_TEST, steps2, 2, level=1, sample=min(SAMPLE, 4))
+            r2 = sums2["raster_ms"] / max(frames2, 1)
+            extra["color_plus_depth"] = {
+                "Mpixels_per_s": round(W * H * steps2 / dt2 / 1e6, 2), "ms_per_step": round(dt2 / steps2 * 1e3, 4),
+                "raster_ms": round(r2, 5), "roofline_frac": round(largest_band_px * 8 / (r2 * 1e-3) / 1e9 / HBM_PEAK_GBS, 5) if r2 > 0 else None}
+
+        # ---- host-visible frames: every band copied into ONE page-locked host image -------------------------------
+        hv_steps = max(min(args.steps, 60), 8)
+        shm_path = None
+        if world > 1:
+            # one image shared by the ranks: a /dev/shm file mapped by every rank and page-locked (hipHostRegister)
+            shm_path = f"/dev/shm/swr_bench_{os.environ.get('MASTER_PORT', '0')}_depth.bin"
+            if rank == 0:
+                with open(shm_path, "wb") as f:
+                    f.truncate(W * H * 4)
+            barrier()
+            depth_img = np.memmap(shm_path, dtype=np.float32, mode="r+", shape=(H, W))
+            swr_amd.host_register(depth_img)
+            color_img = None
+        else:
+            depth_host = swr_amd.HostImage((H, W), np.float32)
+            depth_img = depth_host
+            color_img = None if (flags & S.FLAG_NO_COLOR) else swr_amd.HostImage((H, W, 4), np.uint8)
+        dth, _, _ = run(flags, hv_steps, 3, level=0, present=(color_img, depth_img))
+        hv_bytes = W * H * bytes_per_px
+        extra["host_visible"] = {
+            "Mpixels_per_s": round(W * H * hv_steps / dth / 1e6, 2), "ms_per_step": round(dth / hv_steps * 1e3, 4),
+            "pcie_GBps": round(hv_bytes * hv_steps / dth / 1e9, 2), "bytes_per_frame": hv_bytes, "steps": hv_steps,
+            "note": "draw + swr_present per frame (async D2H of every band into one page-locked host image, colour and depth "
+                    "on two copy streams, device framebuffer double-buffered), swr_present_wait at the end; PCIe-bound"}
+        if world > 1:
+            swr_amd.host_unregister(depth_img)
+            barrier()
+            del depth_img
+            if rank == 0:
+                os.remove(shm_path)
+        else:
+            # the full drop-in call: host pointers in (pageable scene arrays, page-locked images), pixels out
+            rts = []
+            for _ in range(3):
+                t0 = time.perf_counter()
+                ctx.render(scene.vertices, scene.indices, scene.transform, W, H, flags,
+                           color=None if color_img is None else color_img.array, depth=depth_host.array)
+                rts.append(time.perf_counter() - t0)
+            extra["swr_render_ms"] = round(float(np.median(rts)) * 1e3, 3)
+            extra["swr_render_note"] = ("one synchronous swr_render: H2D of 120 MB scene + Morton sort / stream build + draw + "
+                                        "gather into page-locked images; median of 3")
+            depth_host.free()
+            if color_img is not None:
+                color_img.free()
 
     out = {
         "metric": "Mpixels/s at 4K on the 1M-triangle synthetic scene (frames/s in extra)",
-        "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps,
+        "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "latency_ms": round(latency_ms, 4),
+        "latency_note": "ms_per_step is inverse throughput with up to three frames in flight (binning of frames N+1, N+2 beside "
+                        "the raster of frame N); latency_ms is one frame alone, swr_draw -> swr_sync",
         "config": {"workload": f"cfg4: {scene.triangles} random triangles (3 unshared vertices each), {W}x{H}, "
-                               f"z-test, {'colour+depth' if args.color else 'depth-only'}, SplitMix64 seed 0x5EED0004",
-                   "sharding": f"{world} tile-row band(s), scene replicated, no collective"
-                               + (" [REHEARSAL: ranks share GPUs, gloo]" if rehearsal else "")},
+                               f"z-test, {'colour+depth' if args.color else 'depth-only'}, SplitMix64 seed 0x5EED0004, "
+                               f"{scene.meta.get('degenerate_redrawn', 0)} degenerate triangles regenerated (SURVEY 8(d))",
+                   "sharding": (f"{n_gpus} tile-row band(s), scene replicated, no collective; "
+                                + ("one process per GPU (launcher)" if world > 1 else
+                                   ("one process, one multi-device context (swr_config.device_count)" if in_process > 1 else "single context"))
+                                + (" [REHEARSAL: bands share GPUs — not a result]" if rehearsal else ""))},
         "roofline": roofline, "extra": extra,
     }
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and n_gpus == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(scene)
     ctx.close()
     if dist is not None:

@@ -15,13 +15,14 @@
 #ifndef SWR_H_
 #define SWR_H_
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
 extern "C" {
 #endif
 
-#define SWR_ABI_VERSION 2
+#define SWR_ABI_VERSION 3
 
 /* ---- status codes (the reference has no error channel: it fatalError()s / try!s,
  *      Renderer.swift:26,209,239,497; GpuRenderer.swift:20-31,37-38) ------------------ */
@@ -33,7 +34,10 @@ enum {
     SWR_ERR_HIP = -4,           /* HIP runtime error / no device */
     SWR_ERR_UNSUPPORTED = -5,   /* unknown primitive type, too many primitives / vertices */
     SWR_ERR_NO_SCENE = -6,      /* swr_draw before swr_scene_upload / swr_target_set */
-    SWR_ERR_NOMEM = -7
+    SWR_ERR_NOMEM = -7,
+    SWR_ERR_FRAME_DROPPED = -8  /* a frame of an un-waited burst overflowed the (triangle,tile) bins and was rastered
+                                   empty; the bins have been grown, redraw it (only possible when many frames are
+                                   enqueued without swr_sync / swr_present_wait in between) */
 };
 
 /* ---- PrimitiveType (Renderer.swift:174-189).  Only .triangle is on the hot path. ---- */
@@ -125,8 +129,11 @@ typedef struct swr_render_pass {
 } swr_render_pass;
 
 typedef struct swr_config {
-    int32_t  device;     /* HIP device ordinal; -1 = current device */
-    uint32_t reserved;
+    int32_t  device;        /* HIP device ordinal (of the first device); -1 = current device */
+    uint32_t device_count;  /* 0 or 1: one GPU.  N > 1: the context drives N tile-row bands of the framebuffer, band k
+                               on device (device + k) % min(N, visible devices), one host thread and one set of HIP
+                               streams per band, scene replicated, no collective.  With fewer
+                               visible GPUs than N, several bands share a GPU (same code path). */
 } swr_config;
 
 /* Per-kernel device times of the last swr_draw / swr_render on this context, measured with
@@ -144,14 +151,21 @@ typedef struct swr_timings {
 
 typedef struct swr_context swr_context;
 
-/* Library / ABI identification. */
+/* Library / ABI identification; number of visible HIP devices (0 when there is none or no driver). */
 int         swr_abi_version(void);
 const char* swr_version(void);
+int         swr_device_count(void);
 
 /* GpuRenderer() / Renderer() default initialisers (App.swift:148-149) + MTLContext.shared
- * (Metal+Extensions.swift:5-45): device, stream, cached scratch buffers. */
+ * (Metal+Extensions.swift:5-45): device(s), streams, cached scratch buffers.  The reference's one synchronous
+ * draw call (GpuRenderer.swift:35, caller App.swift:185) maps onto ONE context whatever the number of GPUs:
+ * with cfg->device_count = N every entry point below fans out to N per-device sub-contexts. */
 int  swr_context_create(const swr_config* cfg, swr_context** out);
 void swr_context_destroy(swr_context* ctx);
+/* Number of bands (sub-contexts) of the context, and where band `band` lives: its HIP device and the rows
+ * [row_begin,row_end) it owns after swr_target_set.  Any out pointer may be NULL. */
+int  swr_context_bands(const swr_context* ctx);
+int  swr_context_band_info(const swr_context* ctx, int32_t band, int32_t* device, int64_t* row_begin, int64_t* row_end);
 
 /* Last error text for this context (NULL ctx: last error of a failed swr_context_create). */
 const char* swr_last_error(const swr_context* ctx);
@@ -182,13 +196,17 @@ int swr_material_set(swr_context* ctx, const swr_material* material);
 int swr_texture_upload(swr_context* ctx, const void* bgra8, int32_t width, int32_t height);
 
 /* colorBuffer / depthBuffer size (Renderer.swift:192-193).  row_begin/row_end select the
- * tile-row band [row_begin,row_end) of the framebuffer this context (GPU) owns; pass
- * 0,height for the whole image.  row_begin must be a multiple of swr_tile_rows(). */
+ * tile-row band [row_begin,row_end) of the framebuffer this context owns; pass
+ * 0,height for the whole image.  row_begin must be a multiple of swr_tile_rows().  A multi-device
+ * context cuts [row_begin,row_end) into device_count bands of whole tile rows (like swr_band_rows);
+ * a band may be empty when there are more devices than tile rows. */
 int swr_target_set(swr_context* ctx, int64_t width, int64_t height,
                    int64_t row_begin, int64_t row_end);
 
-/* One frame: clear + all triangles (Renderer.swift:204-230) into the device-resident band.
- * Asynchronous on the context stream; swr_sync() or a swr_read_* completes it. */
+/* One frame: clear + all triangles (Renderer.swift:204-230) into the device-resident band(s).
+ * Asynchronous on the context's streams; swr_sync(), swr_present_wait() or a swr_read_* completes it.  On a
+ * multi-device context the call only posts the frame to the per-device threads; an error of the draw itself
+ * (no scene, bad index count, ...) is then returned by the next of those blocking calls. */
 int swr_draw(swr_context* ctx, const float transform[16], uint32_t flags);
 /* Same with RenderPass.primitiveType (Renderer.swift:197, :210-219): .triangle = swr_draw;
  * .vertices plots every vertex reference as a point (Renderer.swift:295-302); .line clears only
@@ -196,8 +214,32 @@ int swr_draw(swr_context* ctx, const float transform[16], uint32_t flags);
 int swr_draw_primitives(swr_context* ctx, const float transform[16], uint32_t flags, int32_t primitive_type);
 int swr_sync(swr_context* ctx);
 
-/* Copy the band's rows into the caller's FULL-size host images (rows [row_begin,row_end) of
- * dst are written, others untouched) — the pinned-memory gather of a multi-GPU frame. */
+/* ---- host-visible frames: the gather ("final image gathered with pinned hipMemcpyAsync") -------------------
+ * The reference's images live in CPU/GPU-shared MTLBuffers (App.swift:59-60,80-101) and are complete on return
+ * of render (scheduleAndWait, Metal+Extensions.swift:57-67).  Here every band is copied device -> host into its
+ * rows of the caller's ONE full-size image; bands are disjoint, so there is nothing to merge.
+ *
+ * swr_host_alloc / swr_host_free: page-locked host memory every GPU can DMA into — allocate the colour and depth
+ *   images with it (what makeBuffer(.storageModeShared) is to the reference).  swr_host_register /
+ *   swr_host_unregister page-lock memory the caller already owns.  (Process-wide, no context needed.)
+ *
+ * swr_present(ctx, color_full, depth_full): enqueue the copy of the frame of the LAST swr_draw — rows
+ *   [row_begin,row_end) of each band — into the caller's full-size images and return at once.  Per device: one
+ *   hipMemcpyAsync per image, colour and depth in flight together on two copy streams, behind that frame's
+ *   raster.  The device framebuffers are double-buffered: the next swr_draw renders into the other one, so the
+ *   copy of frame N overlaps the raster of frame N+1.  Either pointer may be NULL (image not wanted; colour is
+ *   skipped for SWR_FLAG_NO_COLOR frames).  A destination that is not page-locked still works but is staged
+ *   through pinned 8 MiB chunks of the context and blocks the caller.
+ * swr_present_wait(ctx): returns when every enqueued copy has landed: the pixels are host-visible.
+ *
+ * swr_read_color / swr_read_depth: swr_sync + the same copy of one image + wait (rows outside the band(s) are
+ *   left untouched).  swr_render = upload + swr_draw + swr_present + swr_present_wait. */
+void* swr_host_alloc(size_t bytes);
+void  swr_host_free(void* p);
+int   swr_host_register(void* p, size_t bytes);
+int   swr_host_unregister(void* p);
+int swr_present(swr_context* ctx, void* color_full_image, float* depth_full_image);
+int swr_present_wait(swr_context* ctx);
 int swr_read_color(swr_context* ctx, void* dst_full_image);
 int swr_read_depth(swr_context* ctx, float* dst_full_image);
 

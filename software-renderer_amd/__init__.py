@@ -14,9 +14,13 @@ from .binding import (  # noqa: F401
     FLAG_METAL_RULES,
     FLAG_NO_COLOR,
     Context,
+    HostImage,
     SwrError,
     band_rows,
     build,
+    device_count,
+    host_register,
+    host_unregister,
     library_path,
     load_library,
     render,

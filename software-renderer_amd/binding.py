@@ -20,7 +20,8 @@ ABI_SYMBOLS = [
     "swr_render", "swr_scene_upload", "swr_target_set", "swr_draw", "swr_draw_primitives", "swr_sync", "swr_read_color",
     "swr_read_depth", "swr_timing_enable", "swr_get_timings", "swr_timing_totals", "swr_timing_reset", "swr_pipeline_enable", "swr_tile_rows", "swr_tile_cols",
     "swr_band_rows", "swr_scene_attributes", "swr_material_set", "swr_texture_upload",
-    "swr_timing_sample",
+    "swr_timing_sample", "swr_context_bands", "swr_context_band_info", "swr_host_alloc", "swr_host_free",
+    "swr_host_register", "swr_host_unregister", "swr_present", "swr_present_wait", "swr_device_count",
 ]
 
 
@@ -61,7 +62,7 @@ class Material(ctypes.Structure):
 
 
 class Config(ctypes.Structure):
-    _fields_ = [("device", ctypes.c_int32), ("reserved", ctypes.c_uint32)]
+    _fields_ = [("device", ctypes.c_int32), ("device_count", ctypes.c_uint32)]
 
 
 class Timings(ctypes.Structure):
@@ -128,6 +129,19 @@ def load_library():
     L.swr_scene_attributes.argtypes = [vp, vp, i64]
     L.swr_material_set.argtypes = [vp, ctypes.POINTER(Material)]
     L.swr_texture_upload.argtypes = [vp, vp, i32, i32]
+    L.swr_context_bands.argtypes = [vp]
+    L.swr_context_band_info.argtypes = [vp, i32, ctypes.POINTER(i32), ctypes.POINTER(i64), ctypes.POINTER(i64)]
+    L.swr_host_alloc.argtypes = [ctypes.c_size_t]
+    L.swr_host_alloc.restype = vp
+    L.swr_host_free.argtypes = [vp]
+    L.swr_host_free.restype = None
+    L.swr_host_register.argtypes = [vp, ctypes.c_size_t]
+    L.swr_host_unregister.argtypes = [vp]
+    L.swr_present.argtypes = [vp, vp, vp]
+    L.swr_present_wait.argtypes = [vp]
+    for name in ("swr_context_bands", "swr_context_band_info", "swr_host_register", "swr_host_unregister", "swr_present",
+                 "swr_present_wait"):
+        getattr(L, name).restype = ctypes.c_int
     for name in ("swr_scene_attributes", "swr_material_set", "swr_texture_upload"):
         getattr(L, name).restype = ctypes.c_int
     for name in ("swr_context_create", "swr_render", "swr_scene_upload", "swr_target_set", "swr_draw",
@@ -136,6 +150,13 @@ def load_library():
         getattr(L, name).restype = ctypes.c_int
     _lib = L
     return L
+
+
+def device_count() -> int:
+    """Visible HIP devices (0 without a GPU / driver)."""
+    L = load_library()
+    L.swr_device_count.restype = ctypes.c_int
+    return int(L.swr_device_count())
 
 
 def tile_shape():
@@ -152,13 +173,51 @@ def band_rows(height: int, parts: int, part: int):
     return a.value, b.value
 
 
-class Context:
-    """swr_context: one per GPU / per caller thread (GpuRenderer instance, App.swift:149)."""
+class HostImage:
+    """A page-locked host image from swr_host_alloc (what a .storageModeShared MTLBuffer is to the reference,
+    App.swift:59-60), viewed as a NumPy array; every GPU copies its band straight into it (swr_present)."""
 
-    def __init__(self, device: int = -1):
+    def __init__(self, shape, dtype):
+        self._L = load_library()
+        self.shape, self.dtype = tuple(shape), np.dtype(dtype)
+        self.nbytes = int(np.prod(self.shape)) * self.dtype.itemsize
+        self.ptr = self._L.swr_host_alloc(self.nbytes)
+        if not self.ptr:
+            raise SwrError(-7, f"swr_host_alloc({self.nbytes}) failed")
+        buf = (ctypes.c_uint8 * self.nbytes).from_address(self.ptr)
+        self.array = np.frombuffer(buf, dtype=self.dtype).reshape(self.shape)
+
+    def free(self):
+        if self.ptr:
+            self.array = None
+            self._L.swr_host_free(self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def host_register(a: np.ndarray):
+    rc = load_library().swr_host_register(a.ctypes.data, a.nbytes)
+    if rc:
+        raise SwrError(rc, "swr_host_register failed")
+
+
+def host_unregister(a: np.ndarray):
+    load_library().swr_host_unregister(a.ctypes.data)
+
+
+class Context:
+    """swr_context: one per caller thread (GpuRenderer instance, App.swift:149); device_count > 1 = one context
+    driving that many tile-row bands on as many GPUs as are visible."""
+
+    def __init__(self, device: int = -1, device_count: int = 0):
         self._L = load_library()
         self._h = ctypes.c_void_p()
-        cfg = Config(device, 0)
+        cfg = Config(device, device_count)
         rc = self._L.swr_context_create(ctypes.byref(cfg), ctypes.byref(self._h))
         if rc:
             raise SwrError(rc, (self._L.swr_last_error(None) or b"").decode())
@@ -240,6 +299,29 @@ class Context:
 
     def sync(self):
         self._check(self._L.swr_sync(self._h))
+
+    def bands(self):
+        """[(device, row_begin, row_end)] of every band of the context."""
+        out = []
+        for k in range(self._L.swr_context_bands(self._h)):
+            d, a, b = ctypes.c_int32(), ctypes.c_int64(), ctypes.c_int64()
+            self._check(self._L.swr_context_band_info(self._h, k, ctypes.byref(d), ctypes.byref(a), ctypes.byref(b)))
+            out.append((d.value, a.value, b.value))
+        return out
+
+    def present(self, color=None, depth=None):
+        """Enqueue the async copy of the last drawn frame into the caller's full-size images (NumPy arrays or
+        HostImages; page-locked ones make the call non-blocking).  present_wait() makes the pixels visible."""
+        def ptr(x):
+            if x is None:
+                return None
+            return x.ptr if isinstance(x, HostImage) else x.ctypes.data
+        rc = self._L.swr_present(self._h, ptr(color), ptr(depth))
+        if rc:
+            self._check(rc)
+
+    def present_wait(self):
+        self._check(self._L.swr_present_wait(self._h))
 
     def read_color(self, out: np.ndarray | None = None) -> np.ndarray:
         if out is None:

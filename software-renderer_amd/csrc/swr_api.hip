@@ -3,16 +3,32 @@
 // Stands in for GpuRenderer.render(renderPass:) (renderer/GpuRenderer.swift:35-141): where the
 // reference allocates shared MTLBuffers, encodes one compute dispatch per triangle and blocks
 // twice per frame in scheduleAndWait, this context keeps scene, records, bins and the
-// framebuffer band resident in HBM and enqueues four kernels on one HIP stream per frame.
+// framebuffer band resident in HBM and enqueues five kernels on two HIP streams per frame.
+//
+// One swr_context is either
+//   * a single-device context: one GPU, one tile-row band of the framebuffer, or
+//   * a group (swr_config.device_count = N > 1): N single-device sub-contexts, sub-context k owning band k of the
+//     group's target on device (first + k) % devices, each driven by its own host thread.  Every entry point fans
+//     out; the scene is replicated; there is no collective — each device copies its band straight into its rows
+//     of the caller's one host image (swr_present / swr_read_*: hipMemcpyAsync on the device's copy streams).
+//
 // There is no CPU fallback: without a HIP device every computing entry point fails.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <string>
+#include <thread>
+#include <vector>
 
 #include "swr_internal.h"
 
@@ -25,18 +41,91 @@ struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
 };
+
+// One host thread per sub-context of a group: HIP calls of different devices are enqueued in parallel and the
+// caller's thread pays a few microseconds per fan-out instead of N x (nine HIP calls).  Jobs run in FIFO order;
+// asynchronous posts (swr_draw, swr_present) return at once and a failure is kept until the next blocking call.
+struct Worker {
+    std::thread th;
+    std::mutex m;
+    std::condition_variable cv_job, cv_idle;
+    std::deque<std::function<int()>> q;
+    bool busy = false, quit = false;
+    int sticky_rc = 0;
+
+    void start(int device) {
+        th = std::thread([this, device] {
+            (void)hipSetDevice(device);
+            std::unique_lock<std::mutex> lk(m);
+            for (;;) {
+                if (q.empty()) {
+                    // spin briefly before sleeping: frames arrive every few tens of microseconds
+                    lk.unlock();
+                    for (int spin = 0; spin < 4000; spin++) {
+                        __builtin_ia32_pause();
+                        if (pending.load(std::memory_order_acquire)) break;
+                    }
+                    lk.lock();
+                    cv_job.wait(lk, [this] { return quit || !q.empty(); });
+                }
+                if (q.empty() && quit) return;
+                std::function<int()> job = std::move(q.front());
+                q.pop_front();
+                pending.store(!q.empty(), std::memory_order_release);
+                busy = true;
+                lk.unlock();
+                const int rc = job();
+                lk.lock();
+                busy = false;
+                if (rc && !sticky_rc) sticky_rc = rc;
+                if (q.empty()) cv_idle.notify_all();
+            }
+        });
+    }
+    void post(std::function<int()> job) {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            q.push_back(std::move(job));
+            pending.store(true, std::memory_order_release);
+        }
+        cv_job.notify_one();
+    }
+    // wait until every posted job has run; returns (and clears) the first failure since the last drain
+    int drain() {
+        std::unique_lock<std::mutex> lk(m);
+        cv_idle.wait(lk, [this] { return q.empty() && !busy; });
+        const int rc = sticky_rc;
+        sticky_rc = 0;
+        return rc;
+    }
+    void stop() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            quit = true;
+        }
+        cv_job.notify_one();
+        if (th.joinable()) th.join();
+    }
+    std::atomic<bool> pending{false};
+};
 }  // namespace
 
 static_assert(sizeof(swr_render_pass) == 184 && sizeof(swr_material) == 56 && sizeof(swr_vertex_attr) == 32 &&
-              sizeof(swr_vertex) == 32, "include/swr.h layouts (mirrored by the ctypes / Swift bindings)");
+              sizeof(swr_vertex) == 32 && sizeof(swr_config) == 8, "include/swr.h layouts (mirrored by the ctypes / Swift bindings)");
 
 struct swr_context {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
 
+    // ---- group (device_count > 1): the sub-contexts and their host threads; nothing below is used by a group ----
+    std::vector<swr_context*> kids;
+    std::vector<Worker*> workers;
+    Target group_tg{};
+    bool group_has_target = false;
+
     // scene (RenderPass.vertices / .indices)
-    DevBuf vertices, indices, xyz, rgb, idx32, tri_rgb;
+    DevBuf vertices, indices, tri_rgb;
     // the triangle stream built at upload (swr_upload.hip)
     DevBuf tri_xyz, inv, box64, stream_scratch, sort_temp;
     bool reordered = false;
@@ -48,10 +137,26 @@ struct swr_context {
     swr_material material{};            // shader 0 = the reference's passthrough stage
     int32_t tex_w = 0, tex_h = 0;
 
-    // target band (RenderPass.colorBuffer / .depthBuffer)
+    // target band (RenderPass.colorBuffer / .depthBuffer), double-buffered in HBM: swr_present copies the frame just
+    // drawn to the host while the next swr_draw renders into the other buffer
     Target tg{};
     bool has_target = false;
-    DevBuf color, depth;
+    DevBuf color[2], depth[2];
+    int fb_cur = 0;                     // the next swr_draw renders into this buffer
+    int fb_last = 0;                    // the buffer of the last swr_draw (what swr_present / swr_read_* copy)
+    hipStream_t copy_stream[2] = {nullptr, nullptr};   // colour, depth: both images in flight together
+    hipEvent_t frame_done[2] = {nullptr, nullptr};     // raster stream -> copy streams, per framebuffer
+    hipEvent_t copy_done[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [fb][image]: the raster into fb waits for these
+    bool copy_recorded[2][2] = {{false, false}, {false, false}};
+    // pinned staging for destinations that are not page-locked (two 8 MiB chunks per image, D2H / memcpy pipelined)
+    static constexpr size_t STAGE_BYTES = 8u << 20;
+    void* stage[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    hipEvent_t stage_ev[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+    // the last swr_present (for the redo of a frame whose pair list overflowed)
+    void* present_color = nullptr;
+    float* present_depth = nullptr;
+    bool present_pending = false;
+
 #ifndef SWR_NSLOT
 #define SWR_NSLOT 3   // working sets in flight: binning may run up to two frames ahead of the raster (2 -> 3: -3 %)
 #endif
@@ -71,8 +176,14 @@ struct swr_context {
     int last_slot = 0;
     uint32_t capacity = 0;
 
-    uint32_t* h_counters = nullptr;   // pinned, mapped into the device address space
-    uint32_t* h_counters_dev = nullptr;
+    // Pinned, device-mapped words.  h_pairs[f % PAIR_RING] receives the (triangle,tile) pair total of frame f from
+    // the binning kernels (no D2H copy, no host sync per frame); a whole burst of un-waited frames can be checked
+    // for bin overflow afterwards.  h_misc is the upload's index-check word.
+    static constexpr int PAIR_RING = 256;
+    uint32_t* h_pairs = nullptr;
+    uint32_t* h_pairs_dev = nullptr;
+    uint32_t* h_misc = nullptr;
+    uint64_t frames_checked = 0;        // frames [frames_checked, frame_no) have not had their pair total looked at
     // last draw (for the overflow redo and for swr_render)
     float last_m[16]{};
     uint32_t last_flags = 0;
@@ -92,6 +203,19 @@ struct swr_context {
     swr_timings last{};
     double sum_ms[5]{};
     int64_t sum_frames = 0;
+
+    // SWR_HOST_PROFILE=1: wall time of the host side of a frame, split by HIP call group, printed at destroy
+    bool hp_on = false;
+    double hp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t hp_frames = 0;
+    std::chrono::steady_clock::time_point hp_last;
+    void hp_begin() { if (hp_on) hp_last = std::chrono::steady_clock::now(); }
+    void hp_lap(int k) {
+        if (!hp_on) return;
+        const auto now = std::chrono::steady_clock::now();
+        hp_t[k] += std::chrono::duration<double, std::micro>(now - hp_last).count();
+        hp_last = now;
+    }
 };
 
 namespace {
@@ -144,16 +268,20 @@ int sync_streams(swr_context* c) {
     return SWR_OK;
 }
 
-inline int tiles_of(const Target& t) { return t.tiles_x * t.tiles_y; }
+int sync_copies(swr_context* c) {
+    HIP_TRY(c, hipStreamSynchronize(c->copy_stream[0]));
+    HIP_TRY(c, hipStreamSynchronize(c->copy_stream[1]));
+    return SWR_OK;
+}
 
-DeviceFrame make_frame(swr_context* c, int si, const float m[16], uint32_t flags) {
+inline int tiles_of(const Target& t) { return t.tiles_x * t.tiles_y; }
+inline uint32_t& pair_word(swr_context* c, uint64_t frame) { return c->h_pairs[frame % swr_context::PAIR_RING]; }
+
+DeviceFrame make_frame(swr_context* c, int si, uint64_t frame, const float m[16], uint32_t flags) {
     swr_context::Slot& sl = c->slot[si];
     DeviceFrame f{};
     f.vertices = (const swr_vertex*)c->vertices.p;
     f.indices = (const int64_t*)c->indices.p;
-    f.xyz = (const float4*)c->xyz.p;
-    f.rgb = (const float4*)c->rgb.p;
-    f.idx32 = (const uint32_t*)c->idx32.p;
     f.tri_rgb = (const float4*)c->tri_rgb.p;
     f.tri_xyz = (const float4*)c->tri_xyz.p;
     f.inv = (const uint32_t*)c->inv.p;
@@ -169,7 +297,7 @@ DeviceFrame make_frame(swr_context* c, int si, const float m[16], uint32_t flags
     f.geo_full = (GeomFull*)sl.geo_full.p;
     uint32_t* tb = (uint32_t*)sl.tilebuf.p;
     f.counters = tb;
-    f.host_counters = c->h_counters_dev;
+    f.host_counters = c->h_pairs_dev + (frame % swr_context::PAIR_RING);   // word CNT_PAIRS (= 0) of this frame
     f.tile_count = tb + CNT_WORDS;
     f.tile_start = tb + CNT_WORDS + tiles_of(c->tg);
     f.tile_cursor = tb + CNT_WORDS + 2 * tiles_of(c->tg) + 1;
@@ -183,8 +311,8 @@ DeviceFrame make_frame(swr_context* c, int si, const float m[16], uint32_t flags
     f.live_parity = cull_mode != 0 ? 0 : -1;
     f.bins = (uint32_t*)sl.bins.p;
     f.capacity = c->capacity;
-    f.color = (uint8_t*)c->color.p;
-    f.depth = (float*)c->depth.p;
+    f.color = (uint8_t*)c->color[c->fb_cur].p;
+    f.depth = (float*)c->depth[c->fb_cur].p;
     f.tg = c->tg;
     memcpy(f.m, m, sizeof f.m);
     f.flags = flags;
@@ -210,31 +338,15 @@ void harvest(swr_context* c) {
     }
 }
 
-// SWR_HOST_PROFILE=1: wall time of the host side of a frame, split by HIP call group, printed at context destroy.
-struct HostProfile {
-    bool on = getenv("SWR_HOST_PROFILE") && atoi(getenv("SWR_HOST_PROFILE")) == 1;
-    double t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t frames = 0;
-    std::chrono::steady_clock::time_point last;
-    void begin() { if (on) last = std::chrono::steady_clock::now(); }
-    void lap(int k) {
-        if (!on) return;
-        const auto now = std::chrono::steady_clock::now();
-        t[k] += std::chrono::duration<double, std::micro>(now - last).count();
-        last = now;
-    }
-    ~HostProfile() {
-        if (on && frames)
-            fprintf(stderr, "[swr host profile] %llu frames, us/frame: prepare %.2f | wait(slot) %.2f | binning launches %.2f | "
-                            "event record+wait %.2f | raster-stream launches %.2f | record(ras_done) %.2f\n",
-                    (unsigned long long)frames, t[0] / frames, t[1] / frames, t[2] / frames, t[3] / frames, t[4] / frames,
-                    t[5] / frames);
-    }
-};
-static HostProfile g_host_profile;
+// the raster (or point / clear pass) about to write framebuffer `fb` must not overtake a copy still reading it
+int wait_for_copies_of(swr_context* c, int fb, hipStream_t s) {
+    for (int img = 0; img < 2; img++)
+        if (c->copy_recorded[fb][img]) HIP_TRY(c, hipStreamWaitEvent(s, c->copy_done[fb][img], 0));
+    return SWR_OK;
+}
 
 int enqueue_frame(swr_context* c) {
-    g_host_profile.begin();
+    c->hp_begin();
     {
         const BinPlan plan = plan_binning(c->ni / 3, tiles_of(c->tg));
         if (plan.use_lds) {
@@ -249,21 +361,31 @@ int enqueue_frame(swr_context* c) {
             }
         }
     }
+    c->fb_last = c->fb_cur;
+    if (tiles_of(c->tg) == 0) {
+        // an empty band (a group with more sub-contexts than tile rows hands these out): nothing to bin, raster or copy
+        pair_word(c, c->frame_no++) = 0;
+        c->draw_pending = true;
+        return SWR_OK;
+    }
     if (c->last_prim != SWR_PRIMITIVE_TRIANGLE) {
         // .vertices / .line: three small kernels, no binning; the pair counter reads 0
         int rc = sync_streams(c);
         if (rc) return rc;
-        DeviceFrame f = make_frame(c, 0, c->last_m, c->last_flags);
-        c->h_counters[CNT_PAIRS] = 0;
+        const uint64_t frame = c->frame_no++;
+        DeviceFrame f = make_frame(c, 0, frame, c->last_m, c->last_flags);
+        pair_word(c, frame) = 0;
+        if ((rc = wait_for_copies_of(c, c->fb_cur, c->stream))) return rc;
         launch_points_or_lines(f, c->last_prim, c->stream);
         HIP_TRY(c, hipGetLastError());
         c->draw_pending = true;
         return SWR_OK;
     }
-    const int si = (int)(c->frame_no++ % swr_context::NSLOT);
+    const uint64_t frame = c->frame_no++;
+    const int si = (int)(frame % swr_context::NSLOT);
     c->last_slot = si;
     swr_context::Slot& sl = c->slot[si];
-    DeviceFrame f = make_frame(c, si, c->last_m, c->last_flags);
+    DeviceFrame f = make_frame(c, si, frame, c->last_m, c->last_flags);
     hipEvent_t* ev = nullptr;
     if (c->timing >= 2 || (c->timing == 1 && (c->frame_no % (uint64_t)c->timing_every) == 0)) {
         if (c->seq - c->harvested >= (uint64_t)swr_context::RING) {   // ring full: drain it
@@ -276,14 +398,14 @@ int enqueue_frame(swr_context* c) {
         c->seq++;
     }
     hipStream_t sb = c->bin_stream, sr = c->stream;
-    g_host_profile.lap(0);
+    c->hp_lap(0);
     // this slot's buffers are free again once the raster of NSLOT frames ago has read them
     if (sl.ras_recorded && sb != sr) HIP_TRY(c, hipStreamWaitEvent(sb, sl.ras_done, 0));
-    g_host_profile.lap(1);
+    c->hp_lap(1);
     if (!f.plan.use_lds || f.ntri <= 0) {
         // global-atomic fallback: counters must start at zero.  Empty scene: no binning kernel
         // runs at all, so the tile table (counts, starts, counters) is simply zeroed.
-        if (f.ntri <= 0) { int rc = sync_streams(c); if (rc) return rc; c->h_counters[CNT_PAIRS] = 0; }
+        if (f.ntri <= 0) { int rc = sync_streams(c); if (rc) return rc; pair_word(c, frame) = 0; }
         const size_t zero_bytes = (size_t)(CNT_WORDS + 3 * tiles_of(c->tg) + 1) * 4;
         HIP_TRY(c, hipMemsetAsync(sl.tilebuf.p, 0, zero_bytes, sb));
     }
@@ -304,118 +426,89 @@ int enqueue_frame(swr_context* c) {
     const bool sort_on_raster_stream = sort_stream_mode >= 0 ? sort_stream_mode == 1
                                                             : (sb != sr && f.ntri >= 200000 && tiles_of(c->tg) < 3000);
     if (!sort_on_raster_stream) launch_sort_bins(f, sb);
-    g_host_profile.lap(2);
+    c->hp_lap(2);
     if (sb != sr) {
         HIP_TRY(c, hipEventRecord(sl.bin_done, sb));
         HIP_TRY(c, hipStreamWaitEvent(sr, sl.bin_done, 0));
     }
-    g_host_profile.lap(3);
+    c->hp_lap(3);
+    { int rc = wait_for_copies_of(c, c->fb_cur, sr); if (rc) return rc; }
     if (sort_on_raster_stream) launch_sort_bins(f, sr);
     if (ev) HIP_TRY(c, hipEventRecord(ev[3], sr));
     launch_raster(f, sr);
     if (ev) HIP_TRY(c, hipEventRecord(ev[4], sr));
-    g_host_profile.lap(4);
+    c->hp_lap(4);
     if (sb != sr) { HIP_TRY(c, hipEventRecord(sl.ras_done, sr)); sl.ras_recorded = true; }
-    g_host_profile.lap(5);
-    g_host_profile.frames++;
+    c->hp_lap(5);
+    c->hp_frames++;
     HIP_TRY(c, hipGetLastError());
-    c->draw_pending = true;   // the pair total lands in h_counters[CNT_PAIRS] (written by the scan)
+    c->draw_pending = true;   // the pair total lands in the frame's pinned word (written by the scan)
     return SWR_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-int swr_draw_primitives(swr_context* c, const float transform[16], uint32_t flags, int32_t primitive_type);
-
-int swr_abi_version(void) { return SWR_ABI_VERSION; }
-const char* swr_version(void) { return "swr-hip gfx950 0.1 (tile 64x32, wave64 LDS visibility keys)"; }
-int swr_tile_rows(void) { return TILE_H; }
-int swr_tile_cols(void) { return TILE_W; }
-
-const char* swr_last_error(const swr_context* ctx) {
-    return ctx ? ctx->err.c_str() : g_create_error.c_str();
-}
-
-int swr_band_rows(int64_t height, int32_t parts, int32_t part, int64_t* row_begin, int64_t* row_end) {
-    if (height <= 0 || parts <= 0 || part < 0 || part >= parts || !row_begin || !row_end)
-        return SWR_ERR_BAD_ARG;
-    const int64_t trows = (height + TILE_H - 1) / TILE_H;
-    const int64_t t0 = trows * part / parts, t1 = trows * (part + 1) / parts;
-    *row_begin = std::min<int64_t>(t0 * TILE_H, height);
-    *row_end = std::min<int64_t>(t1 * TILE_H, height);
-    return SWR_OK;
-}
-
-int swr_context_create(const swr_config* cfg, swr_context** out) {
-    if (!out) return fail(nullptr, SWR_ERR_BAD_ARG, "swr_context_create: out is NULL");
-    *out = nullptr;
-    int ndev = 0;
-    hipError_t e = hipGetDeviceCount(&ndev);
-    if (e != hipSuccess || ndev <= 0)
-        return fail(nullptr, SWR_ERR_HIP, "no HIP device (%s); this library has no CPU fallback",
-                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
-    int dev = cfg ? cfg->device : -1;
-    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
-    if (dev >= ndev) return fail(nullptr, SWR_ERR_BAD_ARG, "device %d out of range (%d devices)", dev, ndev);
-    swr_context* c = new swr_context();
-    c->device = dev;
-    if ((e = hipSetDevice(dev)) != hipSuccess || (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipHostMalloc((void**)&c->h_counters, CNT_WORDS * 4, hipHostMallocMapped)) != hipSuccess ||
-        (e = hipHostGetDevicePointer((void**)&c->h_counters_dev, c->h_counters, 0)) != hipSuccess) {
-        int rc = fail(nullptr, SWR_ERR_HIP, "context init failed: %s", hipGetErrorString(e));
-        delete c;
-        return rc;
+// Is `p` page-locked memory HIP knows (hipHostMalloc / hipHostRegister)?  Then hipMemcpyAsync into it is a true
+// asynchronous DMA; anything else would be staged by the runtime and block the caller.
+bool is_pinned(const void* p) {
+    hipPointerAttribute_t a;
+    memset(&a, 0, sizeof a);
+    if (hipPointerGetAttributes(&a, p) != hipSuccess) {
+        (void)hipGetLastError();   // unknown pointer = plain pageable memory: not an error
+        return false;
     }
-    memset(c->h_counters, 0, CNT_WORDS * 4);
-    {
-        // SWR_PIPELINE=0: binning and raster share one stream (no overlap of consecutive frames)
-        const char* pl = getenv("SWR_PIPELINE");
-        if (pl && pl[0] == '0') c->bin_stream = c->stream;
-        else {
-            // a plain second stream: stream priorities (binning highest or lowest) were measured to make
-            // no difference to how the two queues share the CUs on this platform
-            if (hipStreamCreateWithFlags(&c->bin_stream, hipStreamNonBlocking) != hipSuccess) c->bin_stream = c->stream;
-            else c->bin_stream_own = c->bin_stream;
-        }
-        for (auto& sl : c->slot) {
-            hipEventCreateWithFlags(&sl.bin_done, hipEventDisableTiming);
-            hipEventCreateWithFlags(&sl.ras_done, hipEventDisableTiming);
+    return a.type == hipMemoryTypeHost;
+}
+
+int ensure_stage(swr_context* c, int img) {
+    for (int k = 0; k < 2; k++) {
+        if (!c->stage[img][k]) HIP_TRY(c, hipHostMalloc(&c->stage[img][k], swr_context::STAGE_BYTES, hipHostMallocDefault));
+        if (!c->stage_ev[img][k]) HIP_TRY(c, hipEventCreateWithFlags(&c->stage_ev[img][k], hipEventDisableTiming));
+    }
+    return SWR_OK;
+}
+
+// Enqueue the copy of image `img` (0 colour, 1 depth) of framebuffer `fb`, this context's band only, into rows
+// [row_begin, row_end) of the caller's full-size host image, on the image's own copy stream, behind frame_done[fb].
+// Page-locked destination: ONE hipMemcpyAsync straight into the caller's rows (returns at once).  Pageable
+// destination: pipelined through two pinned 8 MiB chunks (D2H of chunk k+1 overlaps the memcpy of chunk k; blocks).
+int copy_band(swr_context* c, int fb, int img, void* dst_full) {
+    const size_t row = (size_t)c->tg.width * 4;
+    const size_t bytes = (size_t)(c->tg.row_end - c->tg.row_begin) * row;
+    if (!bytes) return SWR_OK;
+    uint8_t* dst = (uint8_t*)dst_full + (size_t)c->tg.row_begin * row;
+    const uint8_t* src = (const uint8_t*)(img == 0 ? c->color[fb].p : c->depth[fb].p);
+    hipStream_t s = c->copy_stream[img];
+    HIP_TRY(c, hipStreamWaitEvent(s, c->frame_done[fb], 0));
+    if (is_pinned(dst)) {
+        HIP_TRY(c, hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, s));
+    } else {
+        int rc = ensure_stage(c, img);
+        if (rc) return rc;
+        const size_t CH = swr_context::STAGE_BYTES;
+        const size_t n = (bytes + CH - 1) / CH;
+        for (size_t k = 0; k <= n; k++) {
+            if (k < n) {
+                const size_t len = std::min(CH, bytes - k * CH);
+                HIP_TRY(c, hipMemcpyAsync(c->stage[img][k & 1], src + k * CH, len, hipMemcpyDeviceToHost, s));
+                HIP_TRY(c, hipEventRecord(c->stage_ev[img][k & 1], s));
+            }
+            if (k > 0) {
+                const size_t j = k - 1, len = std::min(CH, bytes - j * CH);
+                HIP_TRY(c, hipEventSynchronize(c->stage_ev[img][j & 1]));
+                memcpy(dst + j * CH, c->stage[img][j & 1], len);
+            }
         }
     }
-    for (int r = 0; r < swr_context::RING; r++)
-        for (int i = 0; i < 5; i++) hipEventCreate(&c->ev[r][i]);
-    c->ev_ok = true;
-    *out = c;
+    HIP_TRY(c, hipEventRecord(c->copy_done[fb][img], s));
+    c->copy_recorded[fb][img] = true;
     return SWR_OK;
 }
 
-void swr_context_destroy(swr_context* c) {
-    if (!c) return;
-    hipSetDevice(c->device);
-    if (c->bin_stream) hipStreamSynchronize(c->bin_stream);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->xyz, &c->rgb, &c->idx32, &c->tri_rgb, &c->tri_xyz, &c->inv, &c->box64, &c->stream_scratch, &c->sort_temp, &c->attrs, &c->tri_nrm, &c->texture, &c->texture_bytes, &c->color, &c->depth};
-    for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
-    for (auto& sl : c->slot) {
-        DevBuf* sb[] = {&sl.geo, &sl.geo_full, &sl.ranges, &sl.bins, &sl.bin_matrix, &sl.live, &sl.tilebuf};
-        for (DevBuf* b : sb) if (b->p) hipFree(b->p);
-        if (sl.bin_done) hipEventDestroy(sl.bin_done);
-        if (sl.ras_done) hipEventDestroy(sl.ras_done);
-    }
-    if (c->bin_stream_own) hipStreamDestroy(c->bin_stream_own);
-    if (c->h_counters) hipHostFree(c->h_counters);
-    if (c->ev_ok)
-        for (int r = 0; r < swr_context::RING; r++)
-            for (int i = 0; i < 5; i++) hipEventDestroy(c->ev[r][i]);
-    if (c->stream) hipStreamDestroy(c->stream);
-    delete c;
-}
+// ---- single-device implementations of the entry points ----------------------------------------------------------
+int check_frames(swr_context* c);
+int enqueue_present(swr_context* c, void* color_full, float* depth_full);
 
-int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_count,
-                     const int64_t* indices, int64_t index_count) {
-    if (!c) return SWR_ERR_BAD_ARG;
+int single_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_count,
+                        const int64_t* indices, int64_t index_count) {
     if (vertex_count < 0 || index_count < 0 || (index_count > 0 && (!indices || !vertices)))
         return fail(c, SWR_ERR_BAD_ARG, "swr_scene_upload: bad vertex/index arguments");
     if (index_count / 3 >= 0xFFFFFFFFll || vertex_count > 0xFFFFFFFFll)
@@ -428,9 +521,6 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     int rc;
     if ((rc = ensure(c, c->vertices, (size_t)vertex_count * sizeof(swr_vertex)))) return rc;
     if ((rc = ensure(c, c->indices, (size_t)index_count * 8))) return rc;
-    if ((rc = ensure(c, c->xyz, (size_t)vertex_count * 16))) return rc;
-    if ((rc = ensure(c, c->rgb, (size_t)vertex_count * 16))) return rc;
-    if ((rc = ensure(c, c->idx32, (size_t)index_count * 4))) return rc;
     if ((rc = ensure(c, c->tri_rgb, (size_t)index_count * 16))) return rc;
     const int64_t ntri = index_count / 3;
     // SWR_SORT=0: keep index order (the original index still travels in GeomRec.flags);
@@ -458,14 +548,11 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     // index range check (Swift array subscript would trap, Renderer.swift:226)
     HIP_TRY(c, hipMemsetAsync(c->slot[0].tilebuf.p, 0, CNT_WORDS * 4, c->stream));
     launch_validate_indices((const int64_t*)c->indices.p, index_count, vertex_count, (uint32_t*)c->slot[0].tilebuf.p, c->stream);
-    launch_split_scene((const swr_vertex*)c->vertices.p, vertex_count, (const int64_t*)c->indices.p, index_count,
-                       (float4*)c->xyz.p, (float4*)c->rgb.p, (uint32_t*)c->idx32.p, c->stream);
     HIP_TRY(c, hipGetLastError());
     {
         StreamBuild b{};
         b.vertices = (const swr_vertex*)c->vertices.p; b.nv = vertex_count;
         b.indices = (const int64_t*)c->indices.p; b.ntri = ntri;
-        b.xyz = (const float4*)c->xyz.p;
         b.sort = reorder;
         b.scratch = (uint32_t*)c->stream_scratch.p;
         b.sort_temp = c->sort_temp.p; b.sort_temp_bytes = sort_bytes;
@@ -474,9 +561,9 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
         HIP_TRY(c, launch_build_stream(b, c->stream));
         c->reordered = ntri > 0 && ntri < SORT_MAX_TRIS && sort_mode != -1;   // original index travels in GeomRec.flags
     }
-    HIP_TRY(c, hipMemcpyAsync(c->h_counters, c->slot[0].tilebuf.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(c, hipMemcpyAsync(c->h_misc, c->slot[0].tilebuf.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    if (c->h_counters[CNT_BAD_INDEX])
+    if (c->h_misc[CNT_BAD_INDEX])
         return fail(c, SWR_ERR_INDEX_RANGE, "an index is outside [0, %lld)", (long long)vertex_count);
     c->nv = vertex_count;
     c->ni = index_count;
@@ -485,8 +572,7 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
     return ensure_capacity(c, (uint32_t)std::min<uint64_t>(want, 0xFFFFFFF0ull));
 }
 
-int swr_scene_attributes(swr_context* c, const swr_vertex_attr* attributes, int64_t vertex_count) {
-    if (!c) return SWR_ERR_BAD_ARG;
+int single_scene_attributes(swr_context* c, const swr_vertex_attr* attributes, int64_t vertex_count) {
     if (!c->has_scene) return fail(c, SWR_ERR_NO_SCENE, "swr_scene_attributes needs swr_scene_upload first");
     if (vertex_count != c->nv || (vertex_count > 0 && !attributes))
         return fail(c, SWR_ERR_BAD_ARG, "swr_scene_attributes: %lld attributes for %lld vertices",
@@ -507,8 +593,7 @@ int swr_scene_attributes(swr_context* c, const swr_vertex_attr* attributes, int6
     return SWR_OK;
 }
 
-int swr_material_set(swr_context* c, const swr_material* m) {
-    if (!c) return SWR_ERR_BAD_ARG;
+int single_material_set(swr_context* c, const swr_material* m) {
     if (!m) { c->material = swr_material{}; return SWR_OK; }
     if (m->shader != SWR_SHADER_PASSTHROUGH && m->shader != SWR_SHADER_PHONG && m->shader != SWR_SHADER_TEXTURED_PHONG)
         return fail(c, SWR_ERR_UNSUPPORTED, "unknown shader %d", m->shader);
@@ -518,8 +603,7 @@ int swr_material_set(swr_context* c, const swr_material* m) {
     return SWR_OK;
 }
 
-int swr_texture_upload(swr_context* c, const void* bgra8, int32_t width, int32_t height) {
-    if (!c) return SWR_ERR_BAD_ARG;
+int single_texture_upload(swr_context* c, const void* bgra8, int32_t width, int32_t height) {
     if (!bgra8 || width <= 0 || height <= 0 || width > 16384 || height > 16384)
         return fail(c, SWR_ERR_BAD_ARG, "swr_texture_upload: bad texture %dx%d", width, height);
     HIP_TRY(c, hipSetDevice(c->device));
@@ -536,25 +620,34 @@ int swr_texture_upload(swr_context* c, const void* bgra8, int32_t width, int32_t
     return SWR_OK;
 }
 
-int swr_target_set(swr_context* c, int64_t width, int64_t height, int64_t row_begin, int64_t row_end) {
-    if (!c) return SWR_ERR_BAD_ARG;
+int check_target_args(swr_context* c, int64_t width, int64_t height, int64_t row_begin, int64_t row_end) {
     if (width <= 0 || height <= 0 || width > 65535 || height > 65535)
         return fail(c, SWR_ERR_BAD_ARG, "bad framebuffer size %lldx%lld", (long long)width, (long long)height);
     if (row_begin < 0 || row_end > height || row_begin > row_end || (row_begin % TILE_H) != 0)
         return fail(c, SWR_ERR_BAD_ARG, "bad band [%lld,%lld): row_begin must be a multiple of %d",
                     (long long)row_begin, (long long)row_end, TILE_H);
+    return SWR_OK;
+}
+
+int single_target_set(swr_context* c, int64_t width, int64_t height, int64_t row_begin, int64_t row_end) {
+    int rc = check_target_args(c, width, height, row_begin, row_end);
+    if (rc) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
-    { int rcs = sync_streams(c); if (rcs) return rcs; }
+    if ((rc = sync_streams(c)) || (rc = sync_copies(c))) return rc;
     c->draw_pending = false;
+    c->present_pending = false;
     Target t;
     t.width = (int32_t)width; t.height = (int32_t)height;
     t.row_begin = (int32_t)row_begin; t.row_end = (int32_t)row_end;
     t.tiles_x = (int32_t)((width + TILE_W - 1) / TILE_W);
     t.tiles_y = (int32_t)((row_end - row_begin + TILE_H - 1) / TILE_H);
     const size_t px = (size_t)width * (size_t)(row_end - row_begin);
-    int rc;
-    if ((rc = ensure(c, c->color, px * 4))) return rc;
-    if ((rc = ensure(c, c->depth, px * 4))) return rc;
+    for (int fb = 0; fb < 2; fb++) {
+        if ((rc = ensure(c, c->color[fb], px * 4))) return rc;
+        if ((rc = ensure(c, c->depth[fb], px * 4))) return rc;
+        c->copy_recorded[fb][0] = c->copy_recorded[fb][1] = false;
+    }
+    c->fb_cur = c->fb_last = 0;
     for (auto& sl : c->slot)
         if ((rc = ensure(c, sl.tilebuf, (size_t)(CNT_WORDS + 3 * std::max(1, tiles_of(t)) + 1) * 4))) return rc;
     c->tg = t;
@@ -562,15 +655,18 @@ int swr_target_set(swr_context* c, int64_t width, int64_t height, int64_t row_be
     return SWR_OK;
 }
 
-int swr_draw(swr_context* c, const float transform[16], uint32_t flags) {
-    return swr_draw_primitives(c, transform, flags, SWR_PRIMITIVE_TRIANGLE);
-}
-
-int swr_draw_primitives(swr_context* c, const float transform[16], uint32_t flags, int32_t primitive_type) {
-    if (!c || !transform) return SWR_ERR_BAD_ARG;
+int check_draw_args(swr_context* c, uint32_t flags, int32_t primitive_type) {
     if (primitive_type != SWR_PRIMITIVE_TRIANGLE && primitive_type != SWR_PRIMITIVE_LINE &&
         primitive_type != SWR_PRIMITIVE_VERTICES)
         return fail(c, SWR_ERR_UNSUPPORTED, "unknown primitive type %d", primitive_type);
+    if (flags & ~(uint32_t)(SWR_FLAG_DEPTH_TEST | SWR_FLAG_NO_COLOR | SWR_FLAG_METAL_RULES))
+        return fail(c, SWR_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
+    return SWR_OK;
+}
+
+int single_draw(swr_context* c, const float transform[16], uint32_t flags, int32_t primitive_type) {
+    int rc = check_draw_args(c, flags, primitive_type);
+    if (rc) return rc;
     {
         const int per = primitive_type == SWR_PRIMITIVE_LINE ? 2 : 3;          // verticesCount, Renderer.swift:179-188
         if (c->has_scene && c->ni % per != 0)                                  // assert, Renderer.swift:209
@@ -578,8 +674,6 @@ int swr_draw_primitives(swr_context* c, const float transform[16], uint32_t flag
     }
     if (!c->has_scene || !c->has_target)
         return fail(c, SWR_ERR_NO_SCENE, "swr_draw needs swr_scene_upload and swr_target_set first");
-    if (flags & ~(uint32_t)(SWR_FLAG_DEPTH_TEST | SWR_FLAG_NO_COLOR | SWR_FLAG_METAL_RULES))
-        return fail(c, SWR_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
     if (primitive_type == SWR_PRIMITIVE_TRIANGLE && !(flags & SWR_FLAG_NO_COLOR) &&
         c->material.shader != SWR_SHADER_PASSTHROUGH) {
         if (!c->has_attrs)
@@ -588,61 +682,450 @@ int swr_draw_primitives(swr_context* c, const float transform[16], uint32_t flag
             return fail(c, SWR_ERR_BAD_ARG, "the material needs a texture (swr_texture_upload)");
     }
     HIP_TRY(c, hipSetDevice(c->device));
+    if (c->frame_no - c->frames_checked >= (uint64_t)swr_context::PAIR_RING - 2) {
+        // the ring of per-frame pair totals is about to wrap over frames nobody has looked at: look now (before
+        // the new transform replaces the one a redo of the last frame would need)
+        if ((rc = check_frames(c))) return rc;
+    }
     memcpy(c->last_m, transform, sizeof c->last_m);
     c->last_flags = flags;
     c->last_prim = primitive_type;
     return enqueue_frame(c);
 }
 
-int swr_sync(swr_context* c) {
-    if (!c) return SWR_ERR_BAD_ARG;
+// swr_present of the frame in fb_last: both images in flight together, each on its own copy stream
+int enqueue_present(swr_context* c, void* color_full, float* depth_full) {
+    const int fb = c->fb_last;
+    if (tiles_of(c->tg) == 0) return SWR_OK;
+    HIP_TRY(c, hipEventRecord(c->frame_done[fb], c->stream));
+    int rc;
+    if (color_full && !(c->last_flags & SWR_FLAG_NO_COLOR) && (rc = copy_band(c, fb, 0, color_full))) return rc;
+    if (depth_full && (rc = copy_band(c, fb, 1, depth_full))) return rc;
+    c->fb_cur = fb ^ 1;     // the next frame renders into the other framebuffer while this one is being copied
+    return SWR_OK;
+}
+
+int single_present(swr_context* c, void* color_full, float* depth_full) {
+    if (!c->has_target) return fail(c, SWR_ERR_NO_SCENE, "swr_present needs swr_target_set and a swr_draw first");
+    if (!color_full && !depth_full) return fail(c, SWR_ERR_BAD_ARG, "swr_present: both image pointers are NULL");
     HIP_TRY(c, hipSetDevice(c->device));
+    c->present_color = color_full;
+    c->present_depth = depth_full;
+    c->present_pending = true;
+    return enqueue_present(c, color_full, depth_full);
+}
+
+// Look at the pair totals of every frame since the last look.  The LAST frame is repaired here (bins grown, frame
+// redrawn and, if it had been presented, copied again); an earlier frame of an un-waited burst that overflowed was
+// rastered empty — the bins are grown and SWR_ERR_FRAME_DROPPED is returned once everything else is in order.
+int check_frames(swr_context* c) {
+    bool dropped = false;
+    uint64_t dropped_frame = 0;
+    uint32_t dropped_pairs = 0;
+    auto finish = [&]() -> int {
+        harvest(c);
+        if (dropped)
+            return fail(c, SWR_ERR_FRAME_DROPPED, "frame %llu of an un-waited burst overflowed the bin capacity (%u pairs) and "
+                        "was rastered empty; the bins have been grown — redraw it", (unsigned long long)dropped_frame, dropped_pairs);
+        return SWR_OK;
+    };
     for (int attempt = 0; attempt < 8; attempt++) {
-        { int rcs = sync_streams(c); if (rcs) return rcs; }
-        if (!c->draw_pending) { harvest(c); return SWR_OK; }
-        const uint32_t pairs = c->h_counters[CNT_PAIRS];
-        if (pairs <= c->capacity) {
+        int rc;
+        if ((rc = sync_streams(c))) return rc;
+        if (!c->draw_pending || c->frame_no == 0) { c->frames_checked = c->frame_no; return finish(); }
+        const uint64_t L = c->frame_no - 1;
+        const uint32_t pairs = pair_word(c, L);
+        uint32_t need = pairs;
+        for (uint64_t f = c->frames_checked; f < L; f++) {
+            const uint32_t pf = pair_word(c, f);
+            if (pf > c->capacity) {
+                if (!dropped || pf > dropped_pairs) { dropped_frame = f; dropped_pairs = pf; }
+                dropped = true;
+                need = std::max(need, pf);
+            }
+        }
+        c->frames_checked = L;
+        const uint32_t old_capacity = c->capacity;
+        if (need > old_capacity) {
+            const uint64_t want = (uint64_t)need + need / 4 + 1024;
+            if (want > 0xFFFFFFF0ull) return fail(c, SWR_ERR_UNSUPPORTED, "too many (triangle,tile) pairs: %u", need);
+            if ((rc = sync_copies(c))) return rc;
+            if ((rc = ensure_capacity(c, (uint32_t)want))) return rc;
+        }
+        if (pairs <= old_capacity) {
             c->draw_pending = false;
+            c->frames_checked = c->frame_no;
             c->last.tile_pairs = pairs;
             c->last.tiles = tiles_of(c->tg);
             c->last.triangles = c->ni / 3;
-            harvest(c);
-            return SWR_OK;
+            return finish();
         }
-        // the (triangle,tile) pair list overflowed: grow and redraw the same frame
-        const uint64_t want = (uint64_t)pairs + pairs / 4 + 1024;
-        if (want > 0xFFFFFFF0ull) return fail(c, SWR_ERR_UNSUPPORTED, "too many (triangle,tile) pairs: %u", pairs);
-        int rc = ensure_capacity(c, (uint32_t)want);
-        if (rc) return rc;
+        // the last frame's (triangle,tile) pair list overflowed: redraw it into the same framebuffer, copy it again
+        c->fb_cur = c->fb_last;
         if ((rc = enqueue_frame(c))) return rc;
+        if (c->present_pending && (rc = enqueue_present(c, c->present_color, c->present_depth))) return rc;
     }
     return fail(c, SWR_ERR_HIP, "pair list kept overflowing");
 }
 
+int single_sync(swr_context* c) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    return check_frames(c);
+}
+
+int single_present_wait(swr_context* c) {
+    HIP_TRY(c, hipSetDevice(c->device));
+    int rc = check_frames(c);
+    if (rc) return rc;
+    if ((rc = sync_copies(c))) return rc;
+    c->present_pending = false;
+    return SWR_OK;
+}
+
+int single_read(swr_context* c, int img, void* dst) {
+    if (!c->has_target) return fail(c, SWR_ERR_NO_SCENE, "swr_read_* needs swr_target_set first");
+    int rc = single_sync(c);
+    if (rc) return rc;
+    if (tiles_of(c->tg) == 0) return SWR_OK;
+    const int fb = c->fb_last;
+    HIP_TRY(c, hipEventRecord(c->frame_done[fb], c->stream));
+    if ((rc = copy_band(c, fb, img, dst))) return rc;
+    HIP_TRY(c, hipStreamSynchronize(c->copy_stream[img]));
+    return SWR_OK;
+}
+
+void destroy_single(swr_context* c) {
+    hipSetDevice(c->device);
+    if (c->bin_stream) hipStreamSynchronize(c->bin_stream);
+    if (c->stream) hipStreamSynchronize(c->stream);
+    for (int i = 0; i < 2; i++) if (c->copy_stream[i]) hipStreamSynchronize(c->copy_stream[i]);
+    if (c->hp_on && c->hp_frames)
+        fprintf(stderr, "[swr host profile] device %d, %llu frames, us/frame: prepare %.2f | wait(slot) %.2f | binning launches %.2f | "
+                        "event record+wait %.2f | raster-stream launches %.2f | record(ras_done) %.2f\n", c->device,
+                (unsigned long long)c->hp_frames, c->hp_t[0] / c->hp_frames, c->hp_t[1] / c->hp_frames, c->hp_t[2] / c->hp_frames,
+                c->hp_t[3] / c->hp_frames, c->hp_t[4] / c->hp_frames, c->hp_t[5] / c->hp_frames);
+    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->tri_rgb, &c->tri_xyz, &c->inv, &c->box64, &c->stream_scratch, &c->sort_temp,
+                      &c->attrs, &c->tri_nrm, &c->texture, &c->texture_bytes, &c->color[0], &c->color[1], &c->depth[0], &c->depth[1]};
+    for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
+    for (auto& sl : c->slot) {
+        DevBuf* sb[] = {&sl.geo, &sl.geo_full, &sl.ranges, &sl.bins, &sl.bin_matrix, &sl.live, &sl.tilebuf};
+        for (DevBuf* b : sb) if (b->p) hipFree(b->p);
+        if (sl.bin_done) hipEventDestroy(sl.bin_done);
+        if (sl.ras_done) hipEventDestroy(sl.ras_done);
+    }
+    for (int i = 0; i < 2; i++) {
+        if (c->frame_done[i]) hipEventDestroy(c->frame_done[i]);
+        for (int j = 0; j < 2; j++) {
+            if (c->copy_done[i][j]) hipEventDestroy(c->copy_done[i][j]);
+            if (c->stage[i][j]) hipHostFree(c->stage[i][j]);
+            if (c->stage_ev[i][j]) hipEventDestroy(c->stage_ev[i][j]);
+        }
+        if (c->copy_stream[i]) hipStreamDestroy(c->copy_stream[i]);
+    }
+    if (c->bin_stream_own) hipStreamDestroy(c->bin_stream_own);
+    if (c->h_pairs) hipHostFree(c->h_pairs);
+    if (c->h_misc) hipHostFree(c->h_misc);
+    if (c->ev_ok)
+        for (int r = 0; r < swr_context::RING; r++)
+            for (int i = 0; i < 5; i++) hipEventDestroy(c->ev[r][i]);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int create_single(int dev, swr_context** out) {
+    swr_context* c = new swr_context();
+    c->device = dev;
+    c->hp_on = getenv("SWR_HOST_PROFILE") && atoi(getenv("SWR_HOST_PROFILE")) == 1;
+    hipError_t e;
+    if ((e = hipSetDevice(dev)) != hipSuccess || (e = prepare_device()) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->copy_stream[0], hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipStreamCreateWithFlags(&c->copy_stream[1], hipStreamNonBlocking)) != hipSuccess ||
+        (e = hipHostMalloc((void**)&c->h_pairs, swr_context::PAIR_RING * 4, hipHostMallocMapped)) != hipSuccess ||
+        (e = hipHostGetDevicePointer((void**)&c->h_pairs_dev, c->h_pairs, 0)) != hipSuccess ||
+        (e = hipHostMalloc((void**)&c->h_misc, CNT_WORDS * 4, hipHostMallocDefault)) != hipSuccess) {
+        int rc = fail(nullptr, SWR_ERR_HIP, "context init on device %d failed: %s", dev, hipGetErrorString(e));
+        destroy_single(c);
+        return rc;
+    }
+    memset(c->h_pairs, 0, swr_context::PAIR_RING * 4);
+    memset(c->h_misc, 0, CNT_WORDS * 4);
+    {
+        // SWR_PIPELINE=0: binning and raster share one stream (no overlap of consecutive frames)
+        const char* pl = getenv("SWR_PIPELINE");
+        if (pl && pl[0] == '0') c->bin_stream = c->stream;
+        else {
+            // a plain second stream: stream priorities (binning highest or lowest) were measured to make
+            // no difference to how the two queues share the CUs on this platform
+            if (hipStreamCreateWithFlags(&c->bin_stream, hipStreamNonBlocking) != hipSuccess) c->bin_stream = c->stream;
+            else c->bin_stream_own = c->bin_stream;
+        }
+        for (auto& sl : c->slot) {
+            hipEventCreateWithFlags(&sl.bin_done, hipEventDisableTiming);
+            hipEventCreateWithFlags(&sl.ras_done, hipEventDisableTiming);
+        }
+        for (int i = 0; i < 2; i++) {
+            hipEventCreateWithFlags(&c->frame_done[i], hipEventDisableTiming);
+            for (int j = 0; j < 2; j++) hipEventCreateWithFlags(&c->copy_done[i][j], hipEventDisableTiming);
+        }
+    }
+    for (int r = 0; r < swr_context::RING; r++)
+        for (int i = 0; i < 5; i++) hipEventCreate(&c->ev[r][i]);
+    c->ev_ok = true;
+    *out = c;
+    return SWR_OK;
+}
+
+// ---- group fan-out -----------------------------------------------------------------------------------------------
+inline bool is_group(const swr_context* c) { return !c->kids.empty(); }
+
+// run fn(kid) on every sub-context's own thread and wait; the first failure (and its text) becomes the group's
+template <class F>
+int group_run(swr_context* g, F fn) {
+    const size_t n = g->kids.size();
+    for (size_t k = 0; k < n; k++) {
+        swr_context* kid = g->kids[k];
+        g->workers[k]->post([kid, fn] { return fn(kid); });
+    }
+    int first = SWR_OK;
+    for (size_t k = 0; k < n; k++) {
+        const int rc = g->workers[k]->drain();
+        if (rc && !first) {
+            first = rc;
+            g->err = "device " + std::to_string(g->kids[k]->device) + " (band " + std::to_string(k) + "): " + g->kids[k]->err;
+        }
+    }
+    return first;
+}
+
+// fire and forget (swr_draw / swr_present on a group): errors surface at the next group_run
+template <class F>
+void group_post(swr_context* g, F fn) {
+    for (size_t k = 0; k < g->kids.size(); k++) {
+        swr_context* kid = g->kids[k];
+        g->workers[k]->post([kid, fn] { return fn(kid); });
+    }
+}
+
+// tile-row band k of n inside [row_begin, row_end) (row_begin is tile-aligned)
+void sub_band(int64_t row_begin, int64_t row_end, int n, int k, int64_t* r0, int64_t* r1) {
+    const int64_t trows = (row_end - row_begin + TILE_H - 1) / TILE_H;
+    *r0 = std::min<int64_t>(row_begin + trows * k / n * TILE_H, row_end);
+    *r1 = std::min<int64_t>(row_begin + trows * (k + 1) / n * TILE_H, row_end);
+}
+
+}  // namespace
+
+extern "C" {
+
+int swr_abi_version(void) { return SWR_ABI_VERSION; }
+const char* swr_version(void) { return "swr-hip gfx950 0.2 (tile 64x32, wave64 LDS visibility keys, multi-device bands)"; }
+int swr_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+    return n;
+}
+int swr_tile_rows(void) { return TILE_H; }
+int swr_tile_cols(void) { return TILE_W; }
+
+const char* swr_last_error(const swr_context* ctx) {
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int swr_band_rows(int64_t height, int32_t parts, int32_t part, int64_t* row_begin, int64_t* row_end) {
+    if (height <= 0 || parts <= 0 || part < 0 || part >= parts || !row_begin || !row_end)
+        return SWR_ERR_BAD_ARG;
+    sub_band(0, height, parts, part, row_begin, row_end);
+    return SWR_OK;
+}
+
+int swr_context_create(const swr_config* cfg, swr_context** out) {
+    if (!out) return fail(nullptr, SWR_ERR_BAD_ARG, "swr_context_create: out is NULL");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, SWR_ERR_HIP, "no HIP device (%s); this library has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    int dev = cfg ? cfg->device : -1;
+    if (dev < 0) { if (hipGetDevice(&dev) != hipSuccess) dev = 0; }
+    if (dev >= ndev) return fail(nullptr, SWR_ERR_BAD_ARG, "device %d out of range (%d devices)", dev, ndev);
+    const uint32_t n = cfg ? cfg->device_count : 0;
+    if (n > 64) return fail(nullptr, SWR_ERR_BAD_ARG, "device_count %u > 64", n);
+    if (n <= 1) return create_single(dev, out);
+    // group: sub-context k on device (dev + k) % min(n, visible devices) — with fewer GPUs than bands several bands
+    // share a GPU (same code path; how a 1-GPU box tests the 8-band layout)
+    swr_context* g = new swr_context();
+    g->device = dev;
+    const int span = std::min<int>((int)n, ndev);
+    for (uint32_t k = 0; k < n; k++) {
+        swr_context* kid = nullptr;
+        int rc = create_single((dev + (int)(k % (uint32_t)span)) % ndev, &kid);
+        if (rc) {
+            for (swr_context* x : g->kids) destroy_single(x);
+            delete g;
+            return rc;
+        }
+        g->kids.push_back(kid);
+    }
+    for (uint32_t k = 0; k < n; k++) {
+        Worker* w = new Worker();
+        w->start(g->kids[k]->device);
+        g->workers.push_back(w);
+    }
+    *out = g;
+    return SWR_OK;
+}
+
+void swr_context_destroy(swr_context* c) {
+    if (!c) return;
+    if (is_group(c)) {
+        for (Worker* w : c->workers) { w->drain(); w->stop(); delete w; }
+        for (swr_context* kid : c->kids) destroy_single(kid);
+        delete c;
+        return;
+    }
+    destroy_single(c);
+}
+
+int swr_context_bands(const swr_context* c) { return c ? (is_group(c) ? (int)c->kids.size() : 1) : 0; }
+
+int swr_context_band_info(const swr_context* c, int32_t band, int32_t* device, int64_t* row_begin, int64_t* row_end) {
+    if (!c || band < 0 || band >= swr_context_bands(c)) return SWR_ERR_BAD_ARG;
+    const swr_context* k = is_group(c) ? c->kids[band] : c;
+    if (device) *device = k->device;
+    if (row_begin) *row_begin = k->has_target ? k->tg.row_begin : 0;
+    if (row_end) *row_end = k->has_target ? k->tg.row_end : 0;
+    return SWR_OK;
+}
+
+int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_count,
+                     const int64_t* indices, int64_t index_count) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    if (is_group(c))   // replicated: every device reads the caller's arrays itself, over its own PCIe link
+        return group_run(c, [=](swr_context* k) { return single_scene_upload(k, vertices, vertex_count, indices, index_count); });
+    return single_scene_upload(c, vertices, vertex_count, indices, index_count);
+}
+
+int swr_scene_attributes(swr_context* c, const swr_vertex_attr* attributes, int64_t vertex_count) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    if (is_group(c)) return group_run(c, [=](swr_context* k) { return single_scene_attributes(k, attributes, vertex_count); });
+    return single_scene_attributes(c, attributes, vertex_count);
+}
+
+int swr_material_set(swr_context* c, const swr_material* m) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    if (is_group(c)) {
+        const bool has = m != nullptr;
+        const swr_material copy = has ? *m : swr_material{};
+        return group_run(c, [=](swr_context* k) { return single_material_set(k, has ? &copy : nullptr); });
+    }
+    return single_material_set(c, m);
+}
+
+int swr_texture_upload(swr_context* c, const void* bgra8, int32_t width, int32_t height) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    if (is_group(c)) return group_run(c, [=](swr_context* k) { return single_texture_upload(k, bgra8, width, height); });
+    return single_texture_upload(c, bgra8, width, height);
+}
+
+int swr_target_set(swr_context* c, int64_t width, int64_t height, int64_t row_begin, int64_t row_end) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    if (!is_group(c)) return single_target_set(c, width, height, row_begin, row_end);
+    int rc = check_target_args(c, width, height, row_begin, row_end);
+    if (rc) return rc;
+    const int n = (int)c->kids.size();
+    for (int k = 0; k < n; k++) {
+        int64_t r0, r1;
+        sub_band(row_begin, row_end, n, k, &r0, &r1);
+        swr_context* kid = c->kids[k];
+        c->workers[k]->post([=] { return single_target_set(kid, width, height, r0, r1); });
+    }
+    rc = group_run(c, [](swr_context*) { return SWR_OK; });
+    if (rc) return rc;
+    c->group_tg = Target{(int32_t)width, (int32_t)height, (int32_t)row_begin, (int32_t)row_end, 0, 0};
+    c->group_has_target = true;
+    return SWR_OK;
+}
+
+int swr_draw_primitives(swr_context* c, const float transform[16], uint32_t flags, int32_t primitive_type) {
+    if (!c || !transform) return SWR_ERR_BAD_ARG;
+    if (!is_group(c)) return single_draw(c, transform, flags, primitive_type);
+    int rc = check_draw_args(c, flags, primitive_type);
+    if (rc) return rc;
+    std::array<float, 16> m;
+    memcpy(m.data(), transform, sizeof(float) * 16);
+    group_post(c, [=](swr_context* k) { return single_draw(k, m.data(), flags, primitive_type); });
+    return SWR_OK;      // asynchronous, like the single-device draw: a failure is reported by the next blocking call
+}
+
+int swr_draw(swr_context* c, const float transform[16], uint32_t flags) {
+    return swr_draw_primitives(c, transform, flags, SWR_PRIMITIVE_TRIANGLE);
+}
+
+int swr_sync(swr_context* c) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    if (is_group(c)) return group_run(c, [](swr_context* k) { return single_sync(k); });
+    return single_sync(c);
+}
+
+int swr_present(swr_context* c, void* color_full, float* depth_full) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    if (!is_group(c)) return single_present(c, color_full, depth_full);
+    if (!color_full && !depth_full) return fail(c, SWR_ERR_BAD_ARG, "swr_present: both image pointers are NULL");
+    group_post(c, [=](swr_context* k) { return single_present(k, color_full, depth_full); });
+    return SWR_OK;
+}
+
+int swr_present_wait(swr_context* c) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    if (is_group(c)) return group_run(c, [](swr_context* k) { return single_present_wait(k); });
+    return single_present_wait(c);
+}
+
 int swr_read_color(swr_context* c, void* dst) {
     if (!c || !dst) return SWR_ERR_BAD_ARG;
-    int rc = swr_sync(c);
-    if (rc) return rc;
-    const size_t row = (size_t)c->tg.width * 4;
-    const size_t rows = (size_t)(c->tg.row_end - c->tg.row_begin);
-    if (rows)
-        HIP_TRY(c, hipMemcpy((uint8_t*)dst + (size_t)c->tg.row_begin * row, c->color.p, rows * row, hipMemcpyDeviceToHost));
-    return SWR_OK;
+    if (is_group(c)) return group_run(c, [=](swr_context* k) { return single_read(k, 0, dst); });
+    return single_read(c, 0, dst);
 }
 
 int swr_read_depth(swr_context* c, float* dst) {
     if (!c || !dst) return SWR_ERR_BAD_ARG;
-    int rc = swr_sync(c);
-    if (rc) return rc;
-    const size_t row = (size_t)c->tg.width * 4;
-    const size_t rows = (size_t)(c->tg.row_end - c->tg.row_begin);
-    if (rows)
-        HIP_TRY(c, hipMemcpy((uint8_t*)dst + (size_t)c->tg.row_begin * row, c->depth.p, rows * row, hipMemcpyDeviceToHost));
+    if (is_group(c)) return group_run(c, [=](swr_context* k) { return single_read(k, 1, dst); });
+    return single_read(c, 1, dst);
+}
+
+// ---- page-locked host images ---------------------------------------------------------------------------------------
+void* swr_host_alloc(size_t bytes) {
+    void* p = nullptr;
+    if (bytes == 0) bytes = 16;
+    if (hipHostMalloc(&p, bytes, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    return p;
+}
+
+void swr_host_free(void* p) {
+    if (p) (void)hipHostFree(p);
+}
+
+int swr_host_register(void* p, size_t bytes) {
+    if (!p || !bytes) return SWR_ERR_BAD_ARG;
+    if (hipHostRegister(p, bytes, hipHostRegisterPortable) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(nullptr, SWR_ERR_HIP, "hipHostRegister(%p, %zu) failed", p, bytes);
+    }
     return SWR_OK;
 }
 
+int swr_host_unregister(void* p) {
+    if (!p) return SWR_ERR_BAD_ARG;
+    if (hipHostUnregister(p) != hipSuccess) { (void)hipGetLastError(); return SWR_ERR_HIP; }
+    return SWR_OK;
+}
+
+// ---- instrumentation -------------------------------------------------------------------------------------------------
 int swr_timing_enable(swr_context* c, int enable) {
     if (!c) return SWR_ERR_BAD_ARG;
+    if (is_group(c)) return group_run(c, [=](swr_context* k) { return swr_timing_enable(k, enable); });
     int rc = swr_sync(c);
     if (rc) return rc;
     c->timing = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
@@ -651,6 +1134,7 @@ int swr_timing_enable(swr_context* c, int enable) {
 
 int swr_timing_sample(swr_context* c, int every_nth) {
     if (!c || every_nth < 1) return SWR_ERR_BAD_ARG;
+    if (is_group(c)) return group_run(c, [=](swr_context* k) { return swr_timing_sample(k, every_nth); });
     int rc = swr_sync(c);
     if (rc) return rc;
     c->timing_every = every_nth;
@@ -659,14 +1143,38 @@ int swr_timing_sample(swr_context* c, int every_nth) {
 
 int swr_pipeline_enable(swr_context* c, int enable) {
     if (!c) return SWR_ERR_BAD_ARG;
+    if (is_group(c)) return group_run(c, [=](swr_context* k) { return swr_pipeline_enable(k, enable); });
     int rc = swr_sync(c);
     if (rc) return rc;
     c->bin_stream = (enable && c->bin_stream_own) ? c->bin_stream_own : c->stream;
     return SWR_OK;
 }
 
+// A group reports the slowest band per stage (the frame is done when the last band is) and the sums of the counts.
+static void merge_timings(swr_timings* acc, const swr_timings& t, bool first) {
+    if (first) { *acc = t; return; }
+    acc->setup_bin_ms = std::max(acc->setup_bin_ms, t.setup_bin_ms);
+    acc->scan_ms = std::max(acc->scan_ms, t.scan_ms);
+    acc->scatter_ms = std::max(acc->scatter_ms, t.scatter_ms);
+    acc->raster_ms = std::max(acc->raster_ms, t.raster_ms);
+    acc->total_ms = std::max(acc->total_ms, t.total_ms);
+    acc->tile_pairs += t.tile_pairs;
+    acc->tiles += t.tiles;
+}
+
 int swr_timing_totals(swr_context* c, swr_timings* sum, int64_t* frames) {
     if (!c || !sum || !frames) return SWR_ERR_BAD_ARG;
+    if (is_group(c)) {
+        int rc = swr_sync(c);
+        if (rc) return rc;
+        for (size_t k = 0; k < c->kids.size(); k++) {
+            swr_timings t; int64_t f = 0;
+            if ((rc = swr_timing_totals(c->kids[k], &t, &f))) return rc;
+            merge_timings(sum, t, k == 0);
+            if (k == 0) *frames = f;
+        }
+        return SWR_OK;
+    }
     int rc = swr_sync(c);
     if (rc) return rc;
     *sum = c->last;
@@ -679,6 +1187,7 @@ int swr_timing_totals(swr_context* c, swr_timings* sum, int64_t* frames) {
 
 int swr_timing_reset(swr_context* c) {
     if (!c) return SWR_ERR_BAD_ARG;
+    if (is_group(c)) return group_run(c, [](swr_context* k) { return swr_timing_reset(k); });
     int rc = swr_sync(c);
     if (rc) return rc;
     for (double& v : c->sum_ms) v = 0.0;
@@ -688,6 +1197,16 @@ int swr_timing_reset(swr_context* c) {
 
 int swr_get_timings(swr_context* c, swr_timings* out) {
     if (!c || !out) return SWR_ERR_BAD_ARG;
+    if (is_group(c)) {
+        int rc = swr_sync(c);
+        if (rc) return rc;
+        for (size_t k = 0; k < c->kids.size(); k++) {
+            swr_timings t;
+            if ((rc = swr_get_timings(c->kids[k], &t))) return rc;
+            merge_timings(out, t, k == 0);
+        }
+        return SWR_OK;
+    }
     int rc = swr_sync(c);
     if (rc) return rc;
     *out = c->last;
@@ -712,8 +1231,10 @@ int swr_render(swr_context* c, const swr_render_pass* p) {
     if (p->texture && (rc = swr_texture_upload(c, p->texture, p->tex_width, p->tex_height))) return rc;
     if ((rc = swr_target_set(c, p->width, p->height, 0, p->height))) return rc;
     if ((rc = swr_draw_primitives(c, p->transform, p->flags, p->primitive_type))) return rc;
-    if (!(p->flags & SWR_FLAG_NO_COLOR) && (rc = swr_read_color(c, p->color))) return rc;
-    return swr_read_depth(c, p->depth);
+    // colour and depth leave every device together (two copy streams each); synchronous on return like
+    // scheduleAndWait (Metal+Extensions.swift:57-67)
+    if ((rc = swr_present(c, (p->flags & SWR_FLAG_NO_COLOR) ? nullptr : p->color, p->depth))) return rc;
+    return swr_present_wait(c);
 }
 
 }  // extern "C"

@@ -68,9 +68,6 @@ int live_groups_per_workgroup(int64_t ntri, int G);
 struct DeviceFrame {
     const swr_vertex* vertices;    // as uploaded (AoS)
     const int64_t* indices;
-    const float4* xyz;             // [nv] split positions
-    const float4* rgb;             // [nv] split colours
-    const uint32_t* idx32;         // [ni] narrowed indices
     // the triangle stream (swr_upload.hip): primitives in Morton order of their centroid, de-indexed
     const float4* tri_xyz;         // [ni] corner positions; w of corner 0 = original primitive index (bits)
     const uint32_t* inv;           // [ntri] sorted slot of original primitive o
@@ -106,14 +103,12 @@ struct DeviceFrame {
 
 void launch_validate_indices(const int64_t* indices, int64_t count, int64_t vertex_count,
                              uint32_t* counters, hipStream_t s);
-void launch_split_scene(const swr_vertex* v, int64_t nv, const int64_t* idx, int64_t ni, float4* xyz,
-                        float4* rgb, uint32_t* idx32, hipStream_t s);
+hipError_t prepare_device();      // per-device kernel attributes (after hipSetDevice)
 
 // swr_upload.hip: the once-per-scene triangle stream
 struct StreamBuild {
     const swr_vertex* vertices; int64_t nv;
     const int64_t* indices; int64_t ntri;
-    const float4* xyz;             // split positions (for the bounds / Morton pass)
     bool sort;                     // false: identity order (scenes of 2^24 primitives or more, or SWR_SORT=0)
     uint32_t* scratch;             // 4 * ntri + 8 words
     void* sort_temp; size_t sort_temp_bytes;

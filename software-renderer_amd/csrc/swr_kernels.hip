@@ -141,23 +141,6 @@ __global__ void k_validate_indices(const int64_t* __restrict__ idx, int64_t n, i
     if (bad) atomicOr(&counters[CNT_BAD_INDEX], 1u);
 }
 
-// One-time scene preprocessing at swr_scene_upload: the AoS Vertex array (Renderer.swift:154-157)
-// is split into a position and a colour array — what the reference's own Metal path does every
-// frame on the CPU (GpuRenderer.swift:93-94) — and the Swift-Int indices are narrowed to 32 bits,
-// so the per-frame setup kernel streams 60 MB instead of 120 MB at 1 M triangles.
-__global__ void k_split_scene(const swr_vertex* __restrict__ v, int64_t nv, const int64_t* __restrict__ idx,
-                              int64_t ni, float4* __restrict__ xyz, float4* __restrict__ rgb,
-                              uint32_t* __restrict__ idx32) {
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const float4* vp = reinterpret_cast<const float4*>(v);
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
-        xyz[i] = vp[2 * i];
-        rgb[i] = vp[2 * i + 1];
-    }
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < ni; i += stride)
-        idx32[i] = (uint32_t)idx[i];
-}
-
 // swr_texture_upload: Pixel (b,g,r,a bytes) -> (r,g,b,a) floats, channel / 255.0f (IEEE division, once).
 __global__ void k_texture_to_float(const uint32_t* __restrict__ bgra, int64_t n, float4* __restrict__ out) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -857,7 +840,7 @@ __device__ __forceinline__ float pull_f(int byte_addr, float v) {
     return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
 }
 
-// VAR > 0: timing-only ablations selected with SWR_DEBUG_VARIANT (results invalid):
+// VAR > 0: timing-only ablations (results invalid), instantiated only under -DSWR_ABLATION (`make ablation`):
 //   1 = no LDS atomic, 2 = no pulls/maths/atomic, 3 = no dense loop, 4 = no row walk at all
 #ifndef SWR_RASTER_MIN_WAVES_EXT
 #define SWR_RASTER_MIN_WAVES_EXT 4   // the extended fragment stage's resolve (normal, uv, texels) needs > 96 VGPRs
@@ -1370,11 +1353,11 @@ __global__ void k_clear_band(uint32_t* __restrict__ color, uint32_t* __restrict_
     }
 }
 
-__global__ void k_points(const float4* __restrict__ xyz, const uint32_t* __restrict__ idx32, int64_t ni,
+__global__ void k_points(const swr_vertex* __restrict__ vtx, const int64_t* __restrict__ idx, int64_t ni,
                          float4x4 m, Target tg, uint32_t* __restrict__ order) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= ni) return;
-    const float4 p = xyz[idx32[i]];
+    const float4 p = reinterpret_cast<const float4*>(vtx)[2 * idx[i]];
     const VertexOut vo = vertex_shader(make_float3(p.x, p.y, p.z), make_float3(0, 0, 0), m);   // :160
     const float nx = vo.pos.x / vo.pos.w, ny = vo.pos.y / vo.pos.w;                             // :161
     const float sx = (nx * 0.5f + 0.5f) * (float)tg.width;                                      // :166-168
@@ -1385,14 +1368,14 @@ __global__ void k_points(const float4* __restrict__ xyz, const uint32_t* __restr
     atomicMax(&order[(size_t)(py - tg.row_begin) * (size_t)tg.width + (size_t)px], (uint32_t)(i + 1));
 }
 
-__global__ void k_points_resolve(const float4* __restrict__ rgb, const uint32_t* __restrict__ idx32,
+__global__ void k_points_resolve(const swr_vertex* __restrict__ vtx, const int64_t* __restrict__ idx,
                                  uint32_t* __restrict__ color, uint32_t* __restrict__ depth_bits, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
         const uint32_t o = depth_bits[i];
         uint32_t c = 0u;
         if (o) {
-            const float4 v = rgb[idx32[o - 1]];
+            const float4 v = reinterpret_cast<const float4*>(vtx)[2 * idx[o - 1] + 1];
             VertexOut vin;
             vin.pos = make_float4(0, 0, 0, 1);
             vin.color = make_float3(v.x, v.y, v.z);
@@ -1425,9 +1408,9 @@ void launch_points_or_lines(const DeviceFrame& f, int primitive_type, hipStream_
     float4x4 m;
     for (int c = 0; c < 4; c++)
         m.columns[c] = make_float4(f.m[4 * c + 0], f.m[4 * c + 1], f.m[4 * c + 2], f.m[4 * c + 3]);
-    hipLaunchKernelGGL(k_points, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, s, f.xyz, f.idx32, ni, m, f.tg,
+    hipLaunchKernelGGL(k_points, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, s, f.vertices, f.indices, ni, m, f.tg,
                        (uint32_t*)f.depth);
-    hipLaunchKernelGGL(k_points_resolve, dim3(blocks), dim3(256), 0, s, f.rgb, f.idx32, (uint32_t*)f.color,
+    hipLaunchKernelGGL(k_points_resolve, dim3(blocks), dim3(256), 0, s, f.vertices, f.indices, (uint32_t*)f.color,
                        (uint32_t*)f.depth, n);
 }
 
@@ -1479,15 +1462,19 @@ BinPlan plan_binning(int64_t ntri, int ntiles) {
     return p;
 }
 
-void launch_split_scene(const swr_vertex* v, int64_t nv, const int64_t* idx, int64_t ni, float4* xyz,
-                        float4* rgb, uint32_t* idx32, hipStream_t s) {
-    if (nv <= 0 && ni <= 0) return;
-    hipLaunchKernelGGL(k_split_scene, dim3(2048), dim3(256), 0, s, v, nv, idx, ni, xyz, rgb, idx32);
-}
-
 void launch_texture_to_float(const uint32_t* bgra, int64_t n, float4* out, hipStream_t s) {
     if (n <= 0) return;
     hipLaunchKernelGGL(k_texture_to_float, dim3(2048), dim3(256), 0, s, bgra, n, out);
+}
+
+// The LDS binning kernels may ask for the whole 160 KB of a CU (8K-class tile tables).  The attribute is per device
+// (per loaded code object): swr_context_create calls this after hipSetDevice for every device it opens.
+hipError_t prepare_device() {
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void*)k_setup_hist<BIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_fill_lds<BIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    return hipFuncSetAttribute((const void*)k_fill_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
 void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
@@ -1495,14 +1482,6 @@ void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
     const SetupArgs a = make_setup_args(f);
     const int ntiles = f.tg.tiles_x * f.tg.tiles_y;
     if (f.plan.use_lds) {
-        static bool attr_set = false;
-        if (!attr_set) {
-            (void)hipFuncSetAttribute((const void*)k_setup_hist<BIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_fill_lds<BIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_setup_hist<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            (void)hipFuncSetAttribute((const void*)k_fill_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            attr_set = true;
-        }
         const int per = live_groups_per_workgroup(f.ntri, f.plan.G);
         const size_t lds = f.plan.lds_bytes + (size_t)(per + 1) * 4;
         if (f.plan.threads == 256)
@@ -1583,26 +1562,20 @@ void launch_raster(const DeviceFrame& f, hipStream_t s) {
             hipLaunchKernelGGL((k_raster<false, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         return;
     }
+#ifdef SWR_ABLATION
+    // timing-only ablations of k_raster<ztest> (results invalid): compiled only into lib/libswr_hip_ablation.so
+    // (`make ablation`, used by tools/variants.sh); the product library has neither the kernels nor the switch
     static const int variant = getenv("SWR_DEBUG_VARIANT") ? atoi(getenv("SWR_DEBUG_VARIANT")) : 0;
-    if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 1)
-        hipLaunchKernelGGL((k_raster<true, 1>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 2)
-        hipLaunchKernelGGL((k_raster<true, 2>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 3)
-        hipLaunchKernelGGL((k_raster<true, 3>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 4)
-        hipLaunchKernelGGL((k_raster<true, 4>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 5)
-        hipLaunchKernelGGL((k_raster<true, 5>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 8)
-        hipLaunchKernelGGL((k_raster<true, 8>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 9)
-        hipLaunchKernelGGL((k_raster<true, 9>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 10)
-        hipLaunchKernelGGL((k_raster<true, 10>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-    else if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant == 11)
-        hipLaunchKernelGGL((k_raster<true, 11>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-    else if (f.flags & SWR_FLAG_DEPTH_TEST)
+    if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant > 0) {
+        switch (variant) {
+#define SWR_V(N) case N: hipLaunchKernelGGL((k_raster<true, N>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a); return;
+            SWR_V(1) SWR_V(2) SWR_V(3) SWR_V(4) SWR_V(5) SWR_V(8) SWR_V(9) SWR_V(10) SWR_V(11)
+#undef SWR_V
+            default: break;
+        }
+    }
+#endif
+    if (f.flags & SWR_FLAG_DEPTH_TEST)
         hipLaunchKernelGGL(k_raster<true>, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
     else
         hipLaunchKernelGGL(k_raster<false>, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);

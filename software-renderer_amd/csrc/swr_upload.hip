@@ -41,11 +41,12 @@ __global__ void k_bounds_init(uint32_t* bounds) {
     if (threadIdx.x < 3) bounds[threadIdx.x] = 0xFFFFFFFFu;
     else if (threadIdx.x < 6) bounds[threadIdx.x] = 0u;
 }
-__global__ void k_scene_bounds(const float4* __restrict__ xyz, int64_t nv, uint32_t* __restrict__ bounds) {
+__global__ void k_scene_bounds(const swr_vertex* __restrict__ vtx, int64_t nv, uint32_t* __restrict__ bounds) {
+    const float4* xyz = reinterpret_cast<const float4*>(vtx);     // positions at even float4 slots of the AoS Vertex
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     float lo[3] = {INFINITY, INFINITY, INFINITY}, hi[3] = {-INFINITY, -INFINITY, -INFINITY};
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < nv; i += stride) {
-        const float4 v = xyz[i];
+        const float4 v = xyz[2 * i];
         const float c[3] = {v.x, v.y, v.z};
 #pragma unroll
         for (int k = 0; k < 3; k++)
@@ -77,10 +78,11 @@ __device__ __forceinline__ uint32_t spread10(uint32_t v) {           // 10 bits 
 
 // 30-bit Morton code of the centroid, normalised to the scene's bounding box; ids = 0..ntri-1.
 // A primitive with a bad index or a non-finite vertex gets code 0 (its place does not matter).
-__global__ void k_morton(const float4* __restrict__ xyz, int64_t nv, const int64_t* __restrict__ idx, int64_t ntri,
+__global__ void k_morton(const swr_vertex* __restrict__ vtx, int64_t nv, const int64_t* __restrict__ idx, int64_t ntri,
                          const uint32_t* __restrict__ bounds, uint32_t* __restrict__ codes,
                          uint32_t* __restrict__ ids, int sort) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    const float4* xyz = reinterpret_cast<const float4*>(vtx);
     float lo[3], scale[3];
 #pragma unroll
     for (int k = 0; k < 3; k++) {
@@ -92,7 +94,7 @@ __global__ void k_morton(const float4* __restrict__ xyz, int64_t nv, const int64
         uint32_t code = 0u;
         const int64_t i0 = idx[3 * p], i1 = idx[3 * p + 1], i2 = idx[3 * p + 2];
         if (sort && i0 >= 0 && i0 < nv && i1 >= 0 && i1 < nv && i2 >= 0 && i2 < nv) {
-            const float4 a = xyz[i0], b = xyz[i1], c = xyz[i2];
+            const float4 a = xyz[2 * i0], b = xyz[2 * i1], c = xyz[2 * i2];
             const float cen[3] = {(a.x + b.x + c.x) * (1.0f / 3.0f), (a.y + b.y + c.y) * (1.0f / 3.0f),
                                   (a.z + b.z + c.z) * (1.0f / 3.0f)};
             uint32_t q[3];
@@ -205,8 +207,8 @@ hipError_t launch_build_stream(const StreamBuild& b, hipStream_t s) {
     uint32_t* ids_out = b.scratch + 3 * b.ntri;
     uint32_t* bounds = b.scratch + 4 * b.ntri;
     hipLaunchKernelGGL(k_bounds_init, dim3(1), dim3(64), 0, s, bounds);
-    if (b.nv > 0) hipLaunchKernelGGL(k_scene_bounds, dim3(128), dim3(256), 0, s, b.xyz, b.nv, bounds);   // 6 atomics per wave
-    hipLaunchKernelGGL(k_morton, dim3(2048), dim3(256), 0, s, b.xyz, b.nv, b.indices, b.ntri, bounds, codes_in, ids_in,
+    if (b.nv > 0) hipLaunchKernelGGL(k_scene_bounds, dim3(128), dim3(256), 0, s, b.vertices, b.nv, bounds);   // 6 atomics per wave
+    hipLaunchKernelGGL(k_morton, dim3(2048), dim3(256), 0, s, b.vertices, b.nv, b.indices, b.ntri, bounds, codes_in, ids_in,
                        b.sort ? 1 : 0);
     const uint32_t* perm = ids_in;
     if (b.sort) {

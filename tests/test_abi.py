@@ -21,7 +21,7 @@ def test_header_symbols_are_all_exported(swr):
     swr.build()
     lib = ctypes.CDLL(swr.library_path())
     syms = declared_symbols()
-    assert len(syms) >= 17
+    assert len(syms) >= 33
     for s in syms:
         assert hasattr(lib, s), f"{s} declared in include/swr.h but not exported"
     assert sorted(swr.binding.ABI_SYMBOLS) == syms
@@ -52,6 +52,7 @@ def test_struct_layouts_match_the_swift_types(swr):
     assert B.RenderPass.transform.offset == 88
     assert B.RenderPass.attributes.offset == 152          # extended fragment stage (ABI 2)
     assert ctypes.sizeof(B.Material) == 56
+    assert ctypes.sizeof(B.Config) == 8 and B.Config.device_count.offset == 4   # swr_config (ABI 3: device_count)
     assert ctypes.sizeof(B.Timings) == 5 * 4 + 4 + 3 * 8
 
 

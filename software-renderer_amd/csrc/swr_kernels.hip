@@ -1060,7 +1060,12 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             }
             int y = mine ? ya : 1;
             const int ye = mine ? yb : 0;
-            volatile uint32_t* mk = span_mark[tid >> 6];
+            // marker strip of this wave.  Same-wave producers and consumers: LDS operations of one wave execute in
+            // order, so all that is needed is that the compiler keeps them LDS operations in program order —
+            // wavefront-scope relaxed atomics on the __shared__ array do that (ds_write_b32 / ds_read_b32).  (A
+            // `volatile uint32_t*` here loses the address space: every access became a flat_store / flat_load
+            // with sc0 sc1 followed by s_waitcnt vmcnt(0).)
+            uint32_t* const mk = span_mark[tid >> 6];
             while (VAR != 4 && VAR != 10 && __any(y <= ye)) {
                 // ROWS consecutive rows of every triangle feed one dealing round: more units per round
                 // = fuller dense steps (a partially filled step costs as much as a full one).
@@ -1101,14 +1106,16 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
 #pragma unroll
                         for (int r = 0; r < ROWS; r++) {
                             if (nu[r] > 0 && s0 >= 0 && s0 < 64 * SUPER)
-                                mk[s0] = ((uint32_t)tag << 8) | (uint32_t)(r << 6) | (uint32_t)lane;
+                                __hip_atomic_store(&mk[s0], ((uint32_t)tag << 8) | (uint32_t)(r << 6) | (uint32_t)lane,
+                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                             s0 += nu[r];
                         }
                     }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // compiler-only: stores above, loads below
                     int own[SUPER];
 #pragma unroll
                     for (int k = 0; k < SUPER; k++) {
-                        const uint32_t v = mk[64 * k + lane];
+                        const uint32_t v = __hip_atomic_load(&mk[64 * k + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
                         const int start1 = sbase + 64 * k + lane + 1;
                         own[k] = (v >> 8) == (uint32_t)tag ? (int)((start1 << 8) | (int)(v & 255u)) : 0;
                     }

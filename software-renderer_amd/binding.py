@@ -8,7 +8,8 @@ import subprocess
 import numpy as np
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-_LIB = os.path.join(_PKG, "lib", "libswr_hip.so")
+# SWR_LIBRARY: tools/ only — load another build of the same C-ABI (e.g. lib/libswr_hip_ablation.so of `make ablation`)
+_LIB = os.environ.get("SWR_LIBRARY") or os.path.join(_PKG, "lib", "libswr_hip.so")
 
 FLAG_DEPTH_TEST = 1
 FLAG_NO_COLOR = 2

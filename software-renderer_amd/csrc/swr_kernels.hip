@@ -718,7 +718,7 @@ constexpr unsigned long long KEY_EMPTY = ~0ull;
 struct TriState {
     Chains ch;
     float cfx, cfy;            // float(C) + 0.5 (:89)
-    int cx;                    // C.x (integer), for the exact small-coordinate dx
+    int cx, cy;                // C (integer), for the exact small-coordinate dx / dy
     float t00, t01, t10, t11;
     float za, zb, zc;
     uint32_t prim;
@@ -764,6 +764,7 @@ __device__ __forceinline__ void load_tri(const GeomFull* __restrict__ full, uint
     t.cfx = (float)vx[2] + 0.5f;
     t.cfy = (float)vy[2] + 0.5f;
     t.cx = vx[2];
+    t.cy = vy[2];
     tinv_of(vx[0], vy[0], vx[1], vy[1], vx[2], vy[2], t.t00, t.t01, t.t10, t.t11);
     t.za = q1.x; t.zb = q1.y; t.zc = q1.z;
     t.prim = prim;
@@ -860,6 +861,9 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
 #define SWR_UNIT 4
 #endif
     constexpr int UNIT = SWR_UNIT;    // consecutive pixels of one span handled by one lane of a dense step
+#ifndef SWR_QUEUE
+#define SWR_QUEUE 1   // 1: units dealt through a per-wave LDS ring; 0: the marker-scatter / max-scan dealing of round 1
+#endif
 #ifndef SWR_ROWS
 #define SWR_ROWS 3
 #endif
@@ -868,8 +872,18 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
     constexpr int ROWS = EXT ? 2 : SWR_ROWS;
     __shared__ uint32_t next_chunk;           // work-stealing cursor over the chunks of the sorted bin
     __shared__ float4 tabA[RASTER_THREADS];   // per triangle of the batch: t00, t01, t10, t11
+#if SWR_QUEUE
+    __shared__ float4 tabB[RASTER_THREADS];   //                            za, zb, zc, (C.x - X0) | (C.y - Y0) << 16
+    __shared__ uint32_t tabP[RASTER_THREADS]; //                            original primitive index (the key's low word)
+    // per wave: ring of 4-pixel work units waiting for a lane.  entry = owner lane | xl0 << 6 | yl << 12 | (pixels-1) << 17
+    constexpr int QMAXU = 3;                  // units one lane may queue per row step (wider spans take another step)
+    constexpr int QCAP = 256;                 // >= 63 left over + 64 lanes x QMAXU
+    static_assert(63 + 64 * QMAXU <= QCAP && (QCAP & (QCAP - 1)) == 0, "unit ring size");
+    __shared__ uint32_t queue[RASTER_THREADS / 64][QCAP];
+#else
     __shared__ float4 tabB[RASTER_THREADS];   //                            za, zb, zc, cf.y
     __shared__ uint32_t span_mark[RASTER_THREADS / 64][64 * SUPER];
+#endif
     __shared__ unsigned long long keys[TILE_W * TILE_H];
 
     const int tile = blockIdx.x;
@@ -912,8 +926,10 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
 
     // clear fused into the LDS init (Renderer.clear :205-206, :232-236)
     for (int i = tid; i < TILE_W * TILE_H; i += RASTER_THREADS) keys[i] = KEY_EMPTY;
+#if !SWR_QUEUE
     for (int i = lane; i < 64 * SUPER; i += 64) span_mark[tid >> 6][i] = 0u;
     int tag = 0;               // marker generation of this wave (25 bits: never wraps in one launch)
+#endif
     __syncthreads();
 
     bool first_chunk = true;
@@ -942,7 +958,7 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                 metal_consts(vx, vy, q1.x, q1.y, q1.z, mt);
                 t.t00 = mt.A0; t.t01 = mt.B0; t.t10 = mt.A1; t.t11 = mt.B1;
                 t.za = mt.z0; t.zb = mt.z1; t.zc = mt.z2;
-                t.cfx = mt.p3x; t.cfy = mt.p3y; t.cx = vx[2];
+                t.cfx = mt.p3x; t.cfy = mt.p3y; t.cx = vx[2]; t.cy = vy[2];
                 t.prim = prim;
                 t.ch.small = (__float_as_uint(q1.w) & GEOM_SMALL) != 0;
                 minx = min(vx[0], min(vx[1], vx[2])); maxx = max(vx[0], max(vx[1], vx[2]));
@@ -1044,6 +1060,149 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                 }
             }
         }
+#if SWR_QUEUE
+        // ---- dense phase: lane = triangle for the row walk, lane = 4-pixel unit for the pixel work ------------------
+        // Producer: every lane steps through the rows of ITS OWN (small) triangle; the span of a row is cut into
+        // units of UNIT consecutive pixels and the units are appended to the wave's ring in LDS (exclusive prefix of
+        // the unit counts over the lanes from two ballots).  Consumer: whenever 64 units are waiting (or the rows
+        // have run out) every lane takes one: the owner's constants come from the LDS tables (2 x ds_read_b128 +
+        // ds_read_b32), then UNIT x (weights, depth, ds_min_u64).  Dense steps are always full except the last of a
+        // chunk, and there is no owner search: the unit carries its owner.
+        {
+            const bool mine = have && !big;
+            const int wbase = tid & ~63;
+            // same-wave producers and consumers: LDS operations of one wave execute in order; the wavefront-scope
+            // fences below only keep the compiler from moving the accesses across them
+            if (ZTEST) {
+                tabA[tid] = make_float4(t.t00, t.t01, t.t10, t.t11);
+                tabB[tid] = make_float4(t.za, t.zb, t.zc,
+                                        __int_as_float((int)(((uint32_t)(t.cx - X0) & 0xFFFFu) | ((uint32_t)(t.cy - Y0) << 16))));
+            }
+            tabP[tid] = t.prim;
+            int y = mine ? ya : 1;
+            const int ye = mine ? yb : 0;
+            int xprog = 0;                      // pixels of the current row's span already queued (spans wider than QMAXU units)
+            uint32_t qhead = 0u, qcount = 0u;   // wave-uniform
+            uint32_t* const q = queue[tid >> 6];
+            for (;;) {
+                while (VAR != 4 && VAR != 10 && qcount < 64u && __any(y <= ye)) {
+                    const bool act = y <= ye;
+                    int lo = 0, hi = -1;
+                    if (act) {
+                        if (METAL) { lo = t.ch.s0x; hi = t.ch.s2x; }      // every ROI row spans the ROI's x-range
+                        else row_span_small(t.ch, y, lo, hi);
+                        lo = max(lo, X0);
+                        hi = min(hi, X1);
+                    }
+                    const int xs = lo + xprog;
+                    const int left = act ? max(hi - xs + 1, 0) : 0;       // pixels of the span not yet queued
+                    const int nall = (left + UNIT - 1) / UNIT;
+                    const int nu = min(nall, QMAXU);
+                    static_assert(QMAXU == 3, "the prefix below adds two ballots: unit counts 0..3");
+                    const unsigned long long b0 = __ballot(nu & 1), b1 = __ballot(nu & 2);
+                    const uint32_t pre =
+                        __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
+                        2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
+                    const uint32_t T = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1);
+                    const uint32_t ebase = (uint32_t)lane | ((uint32_t)(xs - X0) << 6) | ((uint32_t)(y - Y0) << 12);
+                    const uint32_t at = qhead + qcount + pre;
+#pragma unroll
+                    for (int u = 0; u < QMAXU; u++)
+                        if (u < nu)
+                            q[(at + (uint32_t)u) & (uint32_t)(QCAP - 1)] =
+                                ebase + ((uint32_t)(UNIT * u) << 6) + ((uint32_t)(min(UNIT, left - UNIT * u) - 1) << 17);
+                    const bool rowdone = nall <= QMAXU;
+                    y += (act && rowdone) ? 1 : 0;
+                    xprog = rowdone ? 0 : xprog + UNIT * QMAXU;
+                    qcount += T;
+                }
+                if (qcount == 0u) break;
+                const uint32_t n = min(qcount, 64u);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (VAR == 3) { qhead += n; qcount -= n; continue; }
+                {
+                    const bool on = (uint32_t)lane < n;
+                    const uint32_t e = q[(qhead + (uint32_t)lane) & (uint32_t)(QCAP - 1)];
+                    const int owner = (int)(e & 63u);
+                    const int lidx0 = (int)((e >> 6) & 2047u);                       // yl * TILE_W + xl0
+                    const int xl0 = (int)((e >> 6) & 63u), yl = (int)((e >> 12) & 31u);
+                    const int nvalid = on ? (int)((e >> 17) & 3u) + 1 : 0;
+                    static_assert(TILE_W == 64 && TILE_H == 32 && UNIT <= 4, "unit entry layout");
+                    const uint32_t oprim = tabP[wbase + owner];
+                    float4 ta = make_float4(0, 0, 0, 0), tb = make_float4(0, 0, 0, 0);
+                    if (ZTEST) { ta = tabA[wbase + owner]; tb = tabB[wbase + owner]; }
+                    const int cp = __float_as_int(tb.w);
+                    const int dxi = xl0 - (int)(short)(cp & 0xFFFF);                 // x - C.x of the unit's first pixel
+                    const int dyi = yl - (cp >> 16);                                 // y - C.y
+                    if (VAR == 2 || VAR == 5) { asm volatile("" ::"v"(ta.x), "v"(ta.y), "v"(ta.z), "v"(ta.w), "v"(tb.x), "v"(tb.y), "v"(tb.z), "v"(dxi), "v"(dyi), "v"(nvalid), "v"(lidx0), "v"(oprim)); }
+                    else if (METAL) {
+                        // Shaders.metal:133-161 with ta = (A0,B0,A1,B1), tb = (z1,z2,z3, .); small integer coordinates:
+                        // (x + .5) - p3.x == (x - p3.x) + .5 exactly
+                        const float dxp0 = (float)dxi + 0.5f;
+                        const float dyp = (float)dyi + 0.5f;
+                        const float divider = ta.w * ta.x - ta.y * ta.z;               // :143
+                        const float n0 = ta.y * dyp, n1 = ta.w * dyp;
+                        // n / divider, correctly rounded, with the divisor's share of the work hoisted out of
+                        // the pixel loop: this is the compiler's own f32 division sequence (rcp, one Newton
+                        // step, quotient, two residual corrections) minus v_div_scale / v_div_fixup, which are
+                        // identities here — GEOM_SMALL triangles have an integer divider with 1 <= |divider| <
+                        // 2^31 and numerators that are 0 or multiples of 1/4 below 2^33, so nothing is scaled,
+                        // denormal, infinite or NaN.  (The wave-cooperative path and the resolve divide plainly.)
+                        const float rc0 = __builtin_amdgcn_rcpf(divider);
+                        const float rcp = __builtin_fmaf(__builtin_fmaf(-divider, rc0, 1.0f), rc0, rc0);
+                        auto div_exact = [&](float nn) {
+                            const float q0 = nn * rcp;
+                            const float q1 = __builtin_fmaf(__builtin_fmaf(-divider, q0, nn), rcp, q0);
+                            return __builtin_fmaf(__builtin_fmaf(-divider, q1, nn), rcp, q1);
+                        };
+#pragma unroll
+                        for (int qq = 0; qq < UNIT; qq++) {
+                            const float dxp = dxp0 + (float)qq;
+                            float w0 = ta.x * dxp + n0;                                // :144
+                            w0 = div_exact(w0);                                        // :145
+                            float w1 = ta.z * dxp + n1;                                // :147
+                            w1 = div_exact(w1);                                        // :148
+                            const float w2 = 1.0f - w0 - w1;                           // :149
+                            const bool inside = 0.0f <= w0 && w0 <= 1.0f && 0.0f <= w1 && w1 <= 1.0f &&
+                                                0.0f <= w2 && w2 <= 1.0f;              // :153
+                            float d = w0 * tb.x + w1 * tb.y + w2 * tb.z;               // :157,:159
+                            const bool live = qq < nvalid && inside && d < INFINITY;
+                            d = d + 0.0f;
+                            const unsigned long long key =
+                                ((unsigned long long)orderable_depth(d) << 32) | (unsigned long long)oprim;
+                            if (live) atomicMin(&keys[lidx0 + qq], key);
+                        }
+                    } else if (ZTEST) {
+                        const float dx0 = (float)dxi;                        // (x + .5) - cf.x, exact: small integers
+                        const float dy = (float)dyi;                         // (y + .5) - cf.y
+                        const float r0 = ta.y * dy, r1 = ta.w * dy;          // t01*dy, t11*dy
+#pragma unroll
+                        for (int qq = 0; qq < UNIT; qq++) {
+                            const float dx = dx0 + (float)qq;                // exact: small integers
+                            const float w0 = ta.x * dx + r0;
+                            const float w1 = ta.z * dx + r1;
+                            const float w2 = 1.0f - w0 - w1;
+                            float d = tb.x * w0 + tb.y * w1 + tb.z * w2;
+                            const bool live = qq < nvalid && d < INFINITY;
+                            d = d + 0.0f;
+                            const unsigned long long key =
+                                ((unsigned long long)orderable_depth(d) << 32) | (unsigned long long)oprim;
+                            if (VAR == 1) { asm volatile("" ::"v"((uint32_t)key), "v"((uint32_t)(key >> 32)), "v"(live)); continue; }
+                            if (live) atomicMin(&keys[lidx0 + qq], key);
+                        }
+                    } else {
+                        const unsigned long long key = (unsigned long long)(0xFFFFFFFFu - oprim);
+#pragma unroll
+                        for (int qq = 0; qq < UNIT; qq++)
+                            if (qq < nvalid) atomicMin(&keys[lidx0 + qq], key);
+                    }
+                }
+                qhead += n;
+                qcount -= n;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next chunk rewrites the tables
+        }
+#else
         // ---- dense phase: lane = triangle for the row walk, lane = 4-pixel unit for the pixel work --
         // Every lane steps through the rows of ITS OWN (small) triangle.  Per row step each span is
         // cut into units of UNIT consecutive pixels; the unit counts are prefix-summed across the
@@ -1215,6 +1374,7 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             }
         }
 
+#endif
         // steal the next chunk (wave-uniform)
         first_chunk = false;
         uint32_t nx = 0u;

@@ -76,6 +76,52 @@ __device__ __forceinline__ int tdiv_small(int n, int d, float rcp_d) {
     return n < 0 ? -q : q;
 }
 
+// Exact a / d and a % d for 0 <= a < 2^31, 0 < d, a / d < 2^20: float estimate (rcp_d ~ 1/d) + integer correction.
+__device__ __forceinline__ void udivmod_small(int a, int d, float rcp_d, int& q, int& r) {
+    q = (int)((float)a * rcp_d);
+    r = a - q * d;
+    if (r < 0) { q -= 1; r += d; }
+    if (r >= d) { q += 1; r -= d; }
+}
+
+// One edge of Renderer.interpolate (:467-494) walked row by row: X(y) = x0 + trunc((x1 - x0) * (y - y0) / (y1 - y0)).
+// The dividend grows by |x1 - x0| per row, so quotient and remainder are carried instead of divided again
+// (a DDA): r += |D| % dy; on r >= dy the quotient takes one extra step.  Exactly the truncating division of :492
+// because the sign of the dividend is the sign of D for every y >= y0.  All state is small integers (GEOM_SMALL).
+struct EdgeStep {
+    int X;          // x0 + sgn * floor(|D| * (y - y0) / dy) at the current row
+    int r;          // (|D| * (y - y0)) % dy
+    int ss, ss1;    // sgn * (|D| / dy) and that plus one more step of sgn
+    int rs, dy;     // |D| % dy, dy
+};
+__device__ __forceinline__ void edge_consts(int xa, int ya, int xb, int yb, EdgeStep& e, float& rcp) {
+    int D = xb - xa, dy = yb - ya;
+    if (dy <= 0) { D = 0; dy = 1; }              // never evaluated by :467-494 (dy == 0 returns the start point)
+    const int a = D < 0 ? -D : D, sgn = D < 0 ? -1 : 1;
+    rcp = __builtin_amdgcn_rcpf((float)dy);
+    int qs;
+    udivmod_small(a, dy, rcp, qs, e.rs);
+    e.dy = dy;
+    e.ss = sgn * qs;
+    e.ss1 = e.ss + sgn;
+    e.X = xa;
+    e.r = 0;
+}
+// move the edge to row ya + k (k >= 0, |D| * k < 2^31)
+__device__ __forceinline__ void edge_jump(int xa, int xb, int k, float rcp, EdgeStep& e) {
+    const int D = xb - xa;
+    const int a = D < 0 ? -D : D, sgn = D < 0 ? -1 : 1;
+    int q;
+    udivmod_small(a * k, e.dy, rcp, q, e.r);
+    e.X = xa + sgn * q;
+}
+__device__ __forceinline__ void edge_next_row(EdgeStep& e) {
+    const int r2 = e.r + e.rs;
+    const bool c = r2 >= e.dy;
+    e.r = c ? r2 - e.dy : r2;
+    e.X += c ? e.ss1 : e.ss;
+}
+
 // Sorted integer vertices + chain data of one triangle, as the span walker needs them.
 struct Chains {
     int s0x, s0y, s1x, s1y, s2x, s2y;
@@ -713,6 +759,10 @@ struct RasterArgs {
 };
 
 constexpr unsigned long long KEY_EMPTY = ~0ull;
+// A pixel has a winner iff the high word of its key is below the orderable image of +inf: the z-mode dense step
+// stores NaN / +inf depths as +inf keys instead of testing every fragment (they lose against any real depth and
+// are never resolved); painter's-mode keys have a zero high word; KEY_EMPTY has all ones.
+constexpr uint32_t KEY_LIVE_BELOW = 0xFF800000u;
 
 // Per-lane triangle state for the span walk.
 struct TriState {
@@ -1084,15 +1134,31 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             int xprog = 0;                      // pixels of the current row's span already queued (spans wider than QMAXU units)
             uint32_t qhead = 0u, qcount = 0u;   // wave-uniform
             uint32_t* const q = queue[tid >> 6];
+            // The two chains of draw(triangle:) (:276-277) as row steppers.  Left chain [S0,S1,S2]: the segment the
+            // first row of the tile falls into, switched to [S1,S2] at the row y == S1.y (:469-475); right chain [S0,S2].
+            EdgeStep eL = {0, 0, 0, 0, 0, 1}, eK = eL, eR = eL;
+            const int s1y = t.ch.s1y, s2y = t.ch.s2y, s2x = t.ch.s2x;
+            if (!METAL && mine) {
+                float rc0, rc1, rcr;
+                EdgeStep e0;
+                edge_consts(t.ch.s0x, t.ch.s0y, t.ch.s1x, t.ch.s1y, e0, rc0);
+                edge_consts(t.ch.s1x, t.ch.s1y, t.ch.s2x, t.ch.s2y, eK, rc1);
+                edge_consts(t.ch.s0x, t.ch.s0y, t.ch.s2x, t.ch.s2y, eR, rcr);
+                const bool in1 = y >= s1y;                       // the tile starts at or below the kink
+                eL = in1 ? eK : e0;
+                edge_jump(in1 ? t.ch.s1x : t.ch.s0x, in1 ? t.ch.s2x : t.ch.s1x, y - (in1 ? t.ch.s1y : t.ch.s0y), in1 ? rc1 : rc0, eL);
+                edge_jump(t.ch.s0x, t.ch.s2x, y - t.ch.s0y, rcr, eR);
+            }
             for (;;) {
                 while (VAR != 4 && VAR != 10 && qcount < 64u && __any(y <= ye)) {
                     const bool act = y <= ye;
                     int lo = 0, hi = -1;
-                    if (act) {
-                        if (METAL) { lo = t.ch.s0x; hi = t.ch.s2x; }      // every ROI row spans the ROI's x-range
-                        else row_span_small(t.ch, y, lo, hi);
-                        lo = max(lo, X0);
-                        hi = min(hi, X1);
+                    if (METAL) {
+                        if (act) { lo = max(t.ch.s0x, X0); hi = min(t.ch.s2x, X1); }   // every ROI row spans the ROI's x-range
+                    } else {
+                        const int L = y >= s2y ? s2x : eL.X;     // :469-480: at and below S2.y the left chain is S2.x
+                        lo = max(min(L, eR.X), X0);              // :278-280 swap, then the tile's scissor
+                        hi = min(max(L, eR.X), X1);
                     }
                     const int xs = lo + xprog;
                     const int left = act ? max(hi - xs + 1, 0) : 0;       // pixels of the span not yet queued
@@ -1112,8 +1178,15 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                             q[(at + (uint32_t)u) & (uint32_t)(QCAP - 1)] =
                                 ebase + ((uint32_t)(UNIT * u) << 6) + ((uint32_t)(min(UNIT, left - UNIT * u) - 1) << 17);
                     const bool rowdone = nall <= QMAXU;
-                    y += (act && rowdone) ? 1 : 0;
                     xprog = rowdone ? 0 : xprog + UNIT * QMAXU;
+                    if (act && rowdone) {
+                        y += 1;
+                        if (!METAL) {
+                            edge_next_row(eL);
+                            edge_next_row(eR);
+                            if (y == s1y) eL = eK;               // the kink: [S1,S2] starts at its first point
+                        }
+                    }
                     qcount += T;
                 }
                 if (qcount == 0u) break;
@@ -1173,7 +1246,8 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                             if (live) atomicMin(&keys[lidx0 + qq], key);
                         }
                     } else if (ZTEST) {
-                        const float dx0 = (float)dxi;                        // (x + .5) - cf.x, exact: small integers
+                        float dx0 = (float)dxi;                              // (x + .5) - cf.x, exact: small integers
+                        asm volatile("" : "+v"(dx0));                        // keep dx0 + q a float add (2 cycles), not add + convert (6)
                         const float dy = (float)dyi;                         // (y + .5) - cf.y
                         const float r0 = ta.y * dy, r1 = ta.w * dy;          // t01*dy, t11*dy
 #pragma unroll
@@ -1182,13 +1256,15 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                             const float w0 = ta.x * dx + r0;
                             const float w1 = ta.z * dx + r1;
                             const float w2 = 1.0f - w0 - w1;
-                            float d = tb.x * w0 + tb.y * w1 + tb.z * w2;
-                            const bool live = qq < nvalid && d < INFINITY;
-                            d = d + 0.0f;
+                            float d = tb.x * w0 + tb.y * w1 + tb.z * w2;     // :257
+                            // A NaN or +inf depth can never pass 'depth < buffer' (:258).  min(d, +inf) turns a NaN into
+                            // +inf, and a key whose depth is +inf counts as "no fragment" at the resolve (KEY_LIVE_BELOW),
+                            // so there is no per-pixel compare; d + 0 turns -0 into +0 (equal under '<').
+                            d = fminf(d + 0.0f, INFINITY);
                             const unsigned long long key =
                                 ((unsigned long long)orderable_depth(d) << 32) | (unsigned long long)oprim;
-                            if (VAR == 1) { asm volatile("" ::"v"((uint32_t)key), "v"((uint32_t)(key >> 32)), "v"(live)); continue; }
-                            if (live) atomicMin(&keys[lidx0 + qq], key);
+                            if (VAR == 1) { asm volatile("" ::"v"((uint32_t)key), "v"((uint32_t)(key >> 32))); continue; }
+                            if (qq < nvalid) atomicMin(&keys[lidx0 + qq], key);
                         }
                     } else {
                         const unsigned long long key = (unsigned long long)(0xFFFFFFFFu - oprim);
@@ -1408,14 +1484,14 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             key4[k] = keys[ly * TILE_W + lx + k];
             const uint32_t prim = ZTEST ? (uint32_t)key4[k] : 0xFFFFFFFFu - (uint32_t)key4[k];
             slot4[k] = prim;
-            if (want_color && a.reordered && key4[k] != KEY_EMPTY) slot4[k] = a.inv[prim];
+            if (want_color && a.reordered && (uint32_t)(key4[k] >> 32) < KEY_LIVE_BELOW) slot4[k] = a.inv[prim];
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const unsigned long long key = key4[k];
             uint32_t c = 0u;               // Pixel(0,0,0,0) (:205)
             float d = INFINITY;            // (:206)
-            if (key != KEY_EMPTY && x + k <= X1) {
+            if ((uint32_t)(key >> 32) < KEY_LIVE_BELOW && x + k <= X1) {
                 const uint32_t prim = ZTEST ? (uint32_t)key : 0xFFFFFFFFu - (uint32_t)key;
                 const uint32_t hi = (uint32_t)(key >> 32);
                 bool need_rec = want_color;

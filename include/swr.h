@@ -35,9 +35,10 @@ enum {
     SWR_ERR_UNSUPPORTED = -5,   /* unknown primitive type, too many primitives / vertices */
     SWR_ERR_NO_SCENE = -6,      /* swr_draw before swr_scene_upload / swr_target_set */
     SWR_ERR_NOMEM = -7,
-    SWR_ERR_FRAME_DROPPED = -8  /* a frame of an un-waited burst overflowed the (triangle,tile) bins and was rastered
-                                   empty; the bins have been grown, redraw it (only possible when many frames are
-                                   enqueued without swr_sync / swr_present_wait in between) */
+    SWR_ERR_FRAME_DROPPED = -8  /* a frame that was copied to the host (swr_present) in an un-waited burst had overflowed
+                                   the (triangle,tile) bins and was rastered empty; the bins have been grown, redraw it.
+                                   (The last frame of a burst is always repaired silently; frames never presented are
+                                   never reported: nobody could see them.) */
 };
 
 /* ---- PrimitiveType (Renderer.swift:174-189).  Only .triangle is on the hot path. ---- */

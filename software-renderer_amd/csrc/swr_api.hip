@@ -182,6 +182,7 @@ struct swr_context {
     static constexpr int PAIR_RING = 256;
     uint32_t* h_pairs = nullptr;
     uint32_t* h_pairs_dev = nullptr;
+    bool frame_presented[PAIR_RING] = {};   // was frame f copied to the host (swr_present)?  Only then can an overflow be seen
     uint32_t* h_misc = nullptr;
     uint64_t frames_checked = 0;        // frames [frames_checked, frame_no) have not had their pair total looked at
     // last draw (for the overflow redo and for swr_render)
@@ -382,6 +383,7 @@ int enqueue_frame(swr_context* c) {
         return SWR_OK;
     }
     const uint64_t frame = c->frame_no++;
+    c->frame_presented[frame % swr_context::PAIR_RING] = false;
     const int si = (int)(frame % swr_context::NSLOT);
     c->last_slot = si;
     swr_context::Slot& sl = c->slot[si];
@@ -702,6 +704,7 @@ int enqueue_present(swr_context* c, void* color_full, float* depth_full) {
     if (color_full && !(c->last_flags & SWR_FLAG_NO_COLOR) && (rc = copy_band(c, fb, 0, color_full))) return rc;
     if (depth_full && (rc = copy_band(c, fb, 1, depth_full))) return rc;
     c->fb_cur = fb ^ 1;     // the next frame renders into the other framebuffer while this one is being copied
+    if (c->frame_no) c->frame_presented[(c->frame_no - 1) % swr_context::PAIR_RING] = true;
     return SWR_OK;
 }
 
@@ -738,7 +741,9 @@ int check_frames(swr_context* c) {
         uint32_t need = pairs;
         for (uint64_t f = c->frames_checked; f < L; f++) {
             const uint32_t pf = pair_word(c, f);
-            if (pf > c->capacity) {
+            if (pf > c->capacity) need = std::max(need, pf);
+            // an earlier frame that overflowed was rastered empty: that matters only if it was copied to the host
+            if (pf > c->capacity && c->frame_presented[f % swr_context::PAIR_RING]) {
                 if (!dropped || pf > dropped_pairs) { dropped_frame = f; dropped_pairs = pf; }
                 dropped = true;
                 need = std::max(need, pf);

@@ -870,29 +870,9 @@ __device__ __forceinline__ int wave_incl_add(int v) {
     SWR_DPP_SCAN("v_add_u32_dpp", v);
     return v;
 }
-__device__ __forceinline__ int wave_incl_max(int v) {   // v >= 0
-    SWR_DPP_SCAN("v_max_i32_dpp", v);
-    return v;
-}
-// two independent max-scans interleaved: each fills the other's DPP hazard slots
-__device__ __forceinline__ void wave_incl_max2(int& a, int& b) {
-#define SWR_MAX2(CTRL)                                                     \
-    "v_max_i32_dpp %0, %0, %0 " CTRL " bank_mask:0xf\n\t"                  \
-    "v_max_i32_dpp %1, %1, %1 " CTRL " bank_mask:0xf\n\t"                  \
-    "s_nop 0\n\t"
-    asm volatile("s_nop 1\n\t" SWR_MAX2("row_shr:1 row_mask:0xf") SWR_MAX2("row_shr:2 row_mask:0xf")
-                 SWR_MAX2("row_shr:4 row_mask:0xf") SWR_MAX2("row_shr:8 row_mask:0xf")
-                 SWR_MAX2("row_bcast:15 row_mask:0xa") SWR_MAX2("row_bcast:31 row_mask:0xc") "s_nop 0"
-                 : "+v"(a), "+v"(b));
-#undef SWR_MAX2
-}
-__device__ __forceinline__ int pull_i(int byte_addr, int v) { return __builtin_amdgcn_ds_bpermute(byte_addr, v); }
-__device__ __forceinline__ float pull_f(int byte_addr, float v) {
-    return __int_as_float(__builtin_amdgcn_ds_bpermute(byte_addr, __float_as_int(v)));
-}
-
 // VAR > 0: timing-only ablations (results invalid), instantiated only under -DSWR_ABLATION (`make ablation`):
-//   1 = no LDS atomic, 2 = no pulls/maths/atomic, 3 = no dense loop, 4 = no row walk at all
+//   1 = no LDS atomic, 2 = no per-pixel maths, 3 = producer only (no unit consumed), 4 = no row walk at all,
+//   8 = no resolve, 9 = no chunk at all, 10 = 4 + 8, 11 = 9 + 8 (tools/ablate.py)
 #ifndef SWR_RASTER_MIN_WAVES_EXT
 #define SWR_RASTER_MIN_WAVES_EXT 4   // the extended fragment stage's resolve (normal, uv, texels) needs > 96 VGPRs
 #endif
@@ -906,23 +886,13 @@ __device__ __forceinline__ float pull_f(int byte_addr, float v) {
 template <bool ZTEST, int VAR = 0, bool METAL = false, bool EXT = false>
 __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SWR_RASTER_MIN_WAVES) void k_raster(RasterArgs a) {
     static_assert(!METAL || ZTEST, "the Metal rules always z-test");
-    constexpr int SUPER = 2;   // dense steps whose owner search is done together
 #ifndef SWR_UNIT
 #define SWR_UNIT 4
 #endif
     constexpr int UNIT = SWR_UNIT;    // consecutive pixels of one span handled by one lane of a dense step
-#ifndef SWR_QUEUE
-#define SWR_QUEUE 1   // 1: units dealt through a per-wave LDS ring; 0: the marker-scatter / max-scan dealing of round 1
-#endif
-#ifndef SWR_ROWS
-#define SWR_ROWS 3
-#endif
-    // consecutive rows of a triangle pooled into one dealing round (<= 4): 3 (whole frame 112.3 -> 110.1 us); the
-    // extended fragment stage's resolve needs the registers, so its instantiations pool 2 (3 would spill 20-28 B/lane)
-    constexpr int ROWS = EXT ? 2 : SWR_ROWS;
+
     __shared__ uint32_t next_chunk;           // work-stealing cursor over the chunks of the sorted bin
     __shared__ float4 tabA[RASTER_THREADS];   // per triangle of the batch: t00, t01, t10, t11
-#if SWR_QUEUE
     __shared__ float4 tabB[RASTER_THREADS];   //                            za, zb, zc, (C.x - X0) | (C.y - Y0) << 16
     __shared__ uint32_t tabP[RASTER_THREADS]; //                            original primitive index (the key's low word)
     // per wave: ring of 4-pixel work units waiting for a lane.  entry = owner lane | xl0 << 6 | yl << 12 | (pixels-1) << 17
@@ -930,10 +900,6 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
     constexpr int QCAP = 256;                 // >= 63 left over + 64 lanes x QMAXU
     static_assert(63 + 64 * QMAXU <= QCAP && (QCAP & (QCAP - 1)) == 0, "unit ring size");
     __shared__ uint32_t queue[RASTER_THREADS / 64][QCAP];
-#else
-    __shared__ float4 tabB[RASTER_THREADS];   //                            za, zb, zc, cf.y
-    __shared__ uint32_t span_mark[RASTER_THREADS / 64][64 * SUPER];
-#endif
     __shared__ unsigned long long keys[TILE_W * TILE_H];
 
     const int tile = blockIdx.x;
@@ -976,10 +942,6 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
 
     // clear fused into the LDS init (Renderer.clear :205-206, :232-236)
     for (int i = tid; i < TILE_W * TILE_H; i += RASTER_THREADS) keys[i] = KEY_EMPTY;
-#if !SWR_QUEUE
-    for (int i = lane; i < 64 * SUPER; i += 64) span_mark[tid >> 6][i] = 0u;
-    int tag = 0;               // marker generation of this wave (25 bits: never wraps in one launch)
-#endif
     __syncthreads();
 
     bool first_chunk = true;
@@ -1110,7 +1072,6 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                 }
             }
         }
-#if SWR_QUEUE
         // ---- dense phase: lane = triangle for the row walk, lane = 4-pixel unit for the pixel work ------------------
         // Producer: every lane steps through the rows of ITS OWN (small) triangle; the span of a row is cut into
         // units of UNIT consecutive pixels and the units are appended to the wave's ring in LDS (exclusive prefix of
@@ -1278,179 +1239,6 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next chunk rewrites the tables
         }
-#else
-        // ---- dense phase: lane = triangle for the row walk, lane = 4-pixel unit for the pixel work --
-        // Every lane steps through the rows of ITS OWN (small) triangle.  Per row step each span is
-        // cut into units of UNIT consecutive pixels; the unit counts are prefix-summed across the
-        // wave and the units of all 64 spans are dealt out densely, one per lane.  The owner lane
-        // and the first unit of its span reach unit j through a start-marker scatter + max-scan;
-        // the owner's per-row word comes by ds_bpermute, its per-triangle constants from a small
-        // LDS table (2 x ds_read_b128); the UNIT pixels are then evaluated with packed f32 maths.
-        {
-            const bool mine = have && !big;
-            const int wbase = tid & ~63;
-            if (ZTEST) {   // same-wave producers and consumers: LDS ops of a wave execute in order
-                tabA[tid] = make_float4(t.t00, t.t01, t.t10, t.t11);
-                tabB[tid] = make_float4(t.za, t.zb, t.zc, t.cfy);
-            }
-            int y = mine ? ya : 1;
-            const int ye = mine ? yb : 0;
-            // marker strip of this wave.  Same-wave producers and consumers: LDS operations of one wave execute in
-            // order, so all that is needed is that the compiler keeps them LDS operations in program order —
-            // wavefront-scope relaxed atomics on the __shared__ array do that (ds_write_b32 / ds_read_b32).  (A
-            // `volatile uint32_t*` here loses the address space: every access became a flat_store / flat_load
-            // with sc0 sc1 followed by s_waitcnt vmcnt(0).)
-            uint32_t* const mk = span_mark[tid >> 6];
-            while (VAR != 4 && VAR != 10 && __any(y <= ye)) {
-                // ROWS consecutive rows of every triangle feed one dealing round: more units per round
-                // = fuller dense steps (a partially filled step costs as much as a full one).
-                int nu[ROWS], packed[ROWS];
-                int nut = 0;
-#pragma unroll
-                for (int r = 0; r < ROWS; r++) {
-                    const int yr = y + r;
-                    const bool act = yr <= ye;
-                    int lo = 0, hi = -1;
-                    if (act) {
-                        if (METAL) { lo = t.ch.s0x; hi = t.ch.s2x; }      // every ROI row spans the ROI's x-range
-                        else row_span_small(t.ch, yr, lo, hi);
-                        lo = max(lo, X0);
-                        hi = min(hi, X1);
-                    }
-                    const int w = act ? max(hi - lo + 1, 0) : 0;
-                    nu[r] = (w + UNIT - 1) / UNIT;                 // units of this span
-                    nut += nu[r];
-                    // per-row word of the owner: tile-local row (5 bits), span start and end (6 + 6 bits),
-                    // lo - C.x (15 bits signed; small coordinates: (x+.5) - (cx+.5) == x - cx exactly)
-                    packed[r] = ((yr - Y0) & 31) | (((lo - X0) & 63) << 5) | (((hi - X0) & 63) << 11) |
-                                ((lo - t.cx) << 17);
-                }
-                const int pin = wave_incl_add(nut);
-                const int pex = pin - nut;
-                const int T = __builtin_amdgcn_readlane(pin, 63);   // units of this round
-                if (VAR == 3) asm volatile("" ::"v"(packed[0]), "v"(packed[ROWS - 1]));
-                // Owner search for SUPER dense steps at once: ONE tagged marker scatter (stale
-                // markers carry an older tag, so the strip is never re-zeroed), then the reads and
-                // two interleaved max-scans.  A marker is tag << 8 | row << 6 | owner lane; the scanned
-                // value is (first unit of the span + 1) << 8 | row << 6 | lane — monotone in the slot.
-                int carry = 0;
-                for (int sbase = 0; VAR != 3 && sbase < T; sbase += 64 * SUPER) {
-                    tag++;
-                    {
-                        int s0 = pex - sbase;
-#pragma unroll
-                        for (int r = 0; r < ROWS; r++) {
-                            if (nu[r] > 0 && s0 >= 0 && s0 < 64 * SUPER)
-                                __hip_atomic_store(&mk[s0], ((uint32_t)tag << 8) | (uint32_t)(r << 6) | (uint32_t)lane,
-                                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                            s0 += nu[r];
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // compiler-only: stores above, loads below
-                    int own[SUPER];
-#pragma unroll
-                    for (int k = 0; k < SUPER; k++) {
-                        const uint32_t v = __hip_atomic_load(&mk[64 * k + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WAVEFRONT);
-                        const int start1 = sbase + 64 * k + lane + 1;
-                        own[k] = (v >> 8) == (uint32_t)tag ? (int)((start1 << 8) | (int)(v & 255u)) : 0;
-                    }
-                    static_assert(SUPER == 2, "the interleaved scan handles two steps");
-                    wave_incl_max2(own[0], own[1]);
-#pragma unroll
-                    for (int k = 0; k < SUPER; k++) {
-                        own[k] = max(own[k], carry);     // span continuing from the previous step
-                        carry = __builtin_amdgcn_readlane(own[k], 63);
-                    }
-#pragma unroll
-                    for (int k = 0; k < SUPER; k++) {
-                        const int base = sbase + 64 * k;
-                        if (base >= T) break;
-                        const int owner = own[k] & 63;
-                        const int orow = (own[k] >> 6) & 3;
-                        const int j = base + lane;
-                        const int offu = j - ((own[k] >> 8) - 1);    // unit index inside the owner's span
-                        if (VAR == 2) { asm volatile("" ::"v"(owner), "v"(offu), "v"(orow)); continue; }
-                        int pk = pull_i(owner << 2, packed[0]);
-#pragma unroll
-                        for (int r = 1; r < ROWS; r++) {
-                            const int pr = pull_i(owner << 2, packed[r]);
-                            pk = orow == r ? pr : pk;
-                        }
-                        const uint32_t oprim = (uint32_t)pull_i(owner << 2, (int)t.prim);
-                        float4 ta = make_float4(0, 0, 0, 0), tb = make_float4(0, 0, 0, 0);
-                        if (ZTEST) { ta = tabA[wbase + owner]; tb = tabB[wbase + owner]; }
-                        const int yl = pk & 31;
-                        const int xl0 = ((pk >> 5) & 63) + UNIT * offu;          // first pixel of the unit
-                        const int nvalid = j < T ? ((pk >> 11) & 63) - xl0 + 1 : 0;   // pixels left in the span
-                        const int lidx0 = yl * TILE_W + xl0;
-                        if (VAR == 5) { asm volatile("" ::"v"(ta.x), "v"(ta.y), "v"(ta.z), "v"(ta.w), "v"(tb.x), "v"(tb.y), "v"(tb.z), "v"(tb.w), "v"(nvalid), "v"(lidx0), "v"(oprim)); continue; }
-                        if (METAL) {
-                            // Shaders.metal:133-161 with ta = (A0,B0,A1,B1), tb = (z1,z2,z3, p3.y)
-                            const float dxp0 = (float)((pk >> 17) + UNIT * offu) + 0.5f;   // (x + .5) - p3.x, exact
-                            const float dyp = ((float)(Y0 + yl) + 0.5f) - tb.w;            // (y + .5) - p3.y
-                            const float divider = ta.w * ta.x - ta.y * ta.z;               // :143
-                            const float n0 = ta.y * dyp, n1 = ta.w * dyp;
-                            // n / divider, correctly rounded, with the divisor's share of the work hoisted out of
-                            // the pixel loop: this is the compiler's own f32 division sequence (rcp, one Newton
-                            // step, quotient, two residual corrections) minus v_div_scale / v_div_fixup, which are
-                            // identities here — GEOM_SMALL triangles have an integer divider with 1 <= |divider| <
-                            // 2^31 and numerators that are 0 or multiples of 1/4 below 2^33, so nothing is scaled,
-                            // denormal, infinite or NaN.  (The wave-cooperative path and the resolve divide plainly.)
-                            const float rc0 = __builtin_amdgcn_rcpf(divider);
-                            const float rcp = __builtin_fmaf(__builtin_fmaf(-divider, rc0, 1.0f), rc0, rc0);
-                            auto div_exact = [&](float n) {
-                                const float q0 = n * rcp;
-                                const float q1 = __builtin_fmaf(__builtin_fmaf(-divider, q0, n), rcp, q0);
-                                return __builtin_fmaf(__builtin_fmaf(-divider, q1, n), rcp, q1);
-                            };
-#pragma unroll
-                            for (int q = 0; q < UNIT; q++) {
-                                const float dxp = dxp0 + (float)q;
-                                float w0 = ta.x * dxp + n0;                                // :144
-                                w0 = div_exact(w0);                                        // :145
-                                float w1 = ta.z * dxp + n1;                                // :147
-                                w1 = div_exact(w1);                                        // :148
-                                const float w2 = 1.0f - w0 - w1;                           // :149
-                                const bool inside = 0.0f <= w0 && w0 <= 1.0f && 0.0f <= w1 && w1 <= 1.0f &&
-                                                    0.0f <= w2 && w2 <= 1.0f;              // :153
-                                float d = w0 * tb.x + w1 * tb.y + w2 * tb.z;               // :157,:159
-                                const bool live = q < nvalid && inside && d < INFINITY;
-                                d = d + 0.0f;
-                                const unsigned long long key =
-                                    ((unsigned long long)orderable_depth(d) << 32) | (unsigned long long)oprim;
-                                if (live) atomicMin(&keys[lidx0 + q], key);
-                            }
-                        } else if (ZTEST) {
-                            const float dx0 = (float)((pk >> 17) + UNIT * offu);
-                            const float dy = ((float)(Y0 + yl) + 0.5f) - tb.w;   // (y + .5) - cf.y
-                            const float r0 = ta.y * dy, r1 = ta.w * dy;          // t01*dy, t11*dy
-#pragma unroll   // 4 pixels in flight: needs 86 VGPRs, hence 5 waves/SIMD (at 6 it spills; `unroll 2` at 6 waves was 2 % slower)
-                            for (int q = 0; q < UNIT; q++) {
-                                const float dx = dx0 + (float)q;                 // exact: small integers
-                                const float w0 = ta.x * dx + r0;
-                                const float w1 = ta.z * dx + r1;
-                                const float w2 = 1.0f - w0 - w1;
-                                float d = tb.x * w0 + tb.y * w1 + tb.z * w2;
-                                const bool live = q < nvalid && d < INFINITY;
-                                d = d + 0.0f;
-                                const unsigned long long key =
-                                    ((unsigned long long)orderable_depth(d) << 32) | (unsigned long long)oprim;
-                                if (VAR == 1) { asm volatile("" ::"v"((uint32_t)key), "v"((uint32_t)(key >> 32)), "v"(live)); continue; }
-                                if (live) atomicMin(&keys[lidx0 + q], key);
-                            }
-                        } else {
-                            const unsigned long long key = (unsigned long long)(0xFFFFFFFFu - oprim);
-#pragma unroll
-                            for (int q = 0; q < UNIT; q++)
-                                if (q < nvalid) atomicMin(&keys[lidx0 + q], key);
-                        }
-                    }
-                }
-                y += ROWS;
-            }
-        }
-
-#endif
         // steal the next chunk (wave-uniform)
         first_chunk = false;
         uint32_t nx = 0u;

@@ -364,7 +364,10 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
 // of rows of the triangle inside the tile minus one (0..31), or CLASS_BIG when its clipped bbox
 // area exceeds BIG_AREA.  k_raster counting-sorts its bin by this key so that the 64 triangles a
 // wave walks together have the same height.
-constexpr int BIG_AREA = 1 << 20;   // clipped bbox area above which a triangle is walked by the whole wave (never: the dense path handles any span)
+#ifndef SWR_BIG_AREA
+#define SWR_BIG_AREA (1 << 20)
+#endif
+constexpr int BIG_AREA = SWR_BIG_AREA;   // clipped bbox area above which a triangle is walked by the whole wave (never: the dense path handles any span)
 constexpr uint32_t CLASS_SHIFT = 26;
 constexpr uint32_t CLASS_BIG = 32;
 constexpr int NUM_CLASSES = 33;
@@ -901,6 +904,14 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
     static_assert(63 + 64 * QMAXU <= QCAP && (QCAP & (QCAP - 1)) == 0, "unit ring size");
     __shared__ uint32_t queue[RASTER_THREADS / 64][QCAP];
     __shared__ unsigned long long keys[TILE_W * TILE_H];
+#ifndef SWR_EARLYZ
+#define SWR_EARLYZ 0   // measured (profiles/r02/earlyz_ab.txt): costs 5 % everywhere, gains nothing — see DESIGN.md §6
+#endif
+    // Early-z (hierarchical): per 16x8 sub-tile (4 x-quarters of each wave-high band of rows) the MAXIMUM key high
+    // word = orderable depth of the farthest pixel, 0xFFFFFFFF while any pixel is still uncovered.  Keys only ever
+    // decrease, so a stale word is still an upper bound: no synchronisation between the waves that refresh and read.
+    constexpr bool EARLYZ = SWR_EARLYZ && ZTEST && !METAL;
+    __shared__ uint32_t zmax_tab[RASTER_THREADS / 64][4];
 
     const int tile = blockIdx.x;
     const int tx = tile % a.tg.tiles_x, ty = tile / a.tg.tiles_x;
@@ -927,10 +938,22 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
     // right here); after that a wave that finishes its chunk steals the next one from an LDS counter.
     // Chunks are heaviest-first, so the stolen ones are the light ones: the waves of a tile finish
     // together instead of waiting at the final barrier for the wave that drew the heavy chunks.
-    const bool spread = gridDim.x <= 1536;   // fewer tiles than the chip holds workgroups (256 CUs x 6)
+    // Few triangles in the tile (one or two chunks): chunk parallelism would leave waves idle while one of them
+    // walks every row and shades every unit (BASELINE configs 2, 3 and 5: 20-30 triangles per tile).  Then the
+    // waves split the ROWS instead: every wave loads every chunk and walks only its quarter of the tile's rows
+    // (the row steppers jump to the first row of the quarter).  Costs the per-triangle setup four times, divides
+    // the row steps and the pixel work by four.
+#ifndef SWR_ROWSPLIT_MAX
+#define SWR_ROWSPLIT_MAX 128
+#endif
+    const bool rowsplit = m <= (uint32_t)SWR_ROWSPLIT_MAX;
+    constexpr int WROWS = TILE_H / (RASTER_THREADS / 64);
+    const int Yw0 = rowsplit ? Y0 + (tid >> 6) * WROWS : Y0;            // this wave's rows of the tile
+    const int Yw1 = rowsplit ? min(Yw0 + WROWS - 1, Y1) : Y1;
+    const bool spread = !rowsplit && gridDim.x <= 1536;   // fewer tiles than the chip holds workgroups (256 CUs x 6)
     const uint32_t csz = spread ? min(64u, max(1u, (m + RASTER_THREADS / 64 - 1) / (RASTER_THREADS / 64))) : 64u;
     const uint32_t nchunks = (m + csz - 1) / csz;
-    uint32_t chunk = (uint32_t)(tid >> 6);
+    uint32_t chunk = rowsplit ? 0u : (uint32_t)(tid >> 6);
     if (tid == 0) next_chunk = RASTER_THREADS / 64;
     const uint32_t slot0 = chunk * csz + (uint32_t)lane;
     const bool have0 = (uint32_t)lane < csz && slot0 < m;
@@ -942,12 +965,30 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
 
     // clear fused into the LDS init (Renderer.clear :205-206, :232-236)
     for (int i = tid; i < TILE_W * TILE_H; i += RASTER_THREADS) keys[i] = KEY_EMPTY;
+    if (EARLYZ && tid < 4 * (RASTER_THREADS / 64)) (&zmax_tab[0][0])[tid] = 0xFFFFFFFFu;
     __syncthreads();
 
     bool first_chunk = true;
     while (VAR != 9 && VAR != 11 && chunk < nchunks) {
         const uint32_t e = chunk * csz + (uint32_t)lane;
         const bool have = (uint32_t)lane < csz && e < m;
+        if (EARLYZ && !first_chunk) {
+            // refresh the four sub-tile words of this wave's band of rows from the keys (16 lanes x 8 pixels each)
+            static_assert(TILE_W == 64 && TILE_H == 8 * (RASTER_THREADS / 64), "sub-tile geometry");
+            const int xq = lane >> 4, ry = (tid >> 6) * 8 + ((lane & 15) >> 1), x0l = xq * 16 + (lane & 1) * 8;
+            const uint4* kp = reinterpret_cast<const uint4*>(&keys[ry * TILE_W + x0l]);
+            const bool rowin = Y0 + ry <= Y1;
+            uint32_t mx = 0u;
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint4 k2 = kp[j];                                     // two keys: high words in .y and .w
+                mx = max(mx, (rowin && X0 + x0l + 2 * j <= X1) ? k2.y : 0u);
+                mx = max(mx, (rowin && X0 + x0l + 2 * j + 1 <= X1) ? k2.w : 0u);
+            }
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
+            if ((lane & 15) == 0) __hip_atomic_store(&zmax_tab[tid >> 6][xq], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
         TriState t;
         int ya = 1, yb = 0, bxa = 0, bxb = -1;
         bool big = false;
@@ -982,13 +1023,42 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             }
             // visibility keys order by the ORIGINAL primitive index (Renderer.swift:222,258)
             if (a.reordered) t.prim = __float_as_uint(q1.w) >> GEOM_ORIG_SHIFT;
-            ya = max(t.ch.s0y, Y0);
-            yb = min(t.ch.s2y, Y1);
+            ya = max(t.ch.s0y, Yw0);
+            yb = min(t.ch.s2y, Yw1);
             bxa = max(minx, X0);
             bxb = min(maxx, X1);
             // the dense path below needs the exact small-coordinate arithmetic; everything else
             // (huge extents, large clipped area) is walked cooperatively in phase 2
             big = !t.ch.small || maxx - minx >= 16384 || (yb - ya + 1) * (bxb - bxa + 1) > BIG_AREA;
+            if (EARLYZ && !first_chunk && !big && ya <= yb && bxa <= bxb) {
+                // Hierarchical z: drop the triangle (for this tile / this wave's rows) when a lower bound of its depth
+                // over every pixel it can cover — its clipped bounding box: spans include pixels OUTSIDE the true
+                // triangle with extrapolated weights (:252-266), so min(za,zb,zc) is NOT a bound — lies strictly above
+                // the farthest depth already stored in the sub-tiles under that box.  Strict '>': at equal depth the
+                // index still decides (:258).
+                const int sq0 = (bxa - X0) >> 4, sq1 = (bxb - X0) >> 4, sb0 = (ya - Y0) >> 3, sb1 = (yb - Y0) >> 3;
+                if (sb1 - sb0 <= 1) {
+                    uint32_t zm = 0u;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const uint32_t v0 = __hip_atomic_load(&zmax_tab[sb0][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        const uint32_t v1 = __hip_atomic_load(&zmax_tab[sb1][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        if (q >= sq0 && q <= sq1) zm = max(zm, max(v0, v1));
+                    }
+                    if (zm < KEY_LIVE_BELOW) {      // every pixel of those sub-tiles already holds a finite depth
+                        // depth = zc + (za - zc) w0 + (zb - zc) w1 with |w0| <= |t00| DX + |t01| DY over the box (affine in
+                        // x, y), likewise w1; plus a generous bound on the rounding of the float evaluation itself
+                        const float DX = (float)max(abs(bxa - t.cx), abs(bxb - t.cx));
+                        const float DY = (float)max(abs(ya - t.cy), abs(yb - t.cy));
+                        const float A0 = fabsf(t.t00) * DX + fabsf(t.t01) * DY;
+                        const float A1 = fabsf(t.t10) * DX + fabsf(t.t11) * DY;
+                        const float dz = (fabsf(t.za - t.zc) * A0 + fabsf(t.zb - t.zc) * A1) * 1.0009765625f;
+                        const float mg = 1.9073486328125e-06f * (fabsf(t.za) * A0 + fabsf(t.zb) * A1 + fabsf(t.zc) * (1.0f + A0 + A1)) + 1e-37f;
+                        const float zlo = (t.zc - dz) - mg;
+                        if (zlo == zlo && orderable_depth(zlo + 0.0f) > zm) yb = ya - 1;   // NaN anywhere: keep the triangle
+                    }
+                }
+            }
         }
 
         // ---- big or huge-coordinate triangles first, one at a time, walked by the whole wave ----
@@ -1239,11 +1309,15 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next chunk rewrites the tables
         }
-        // steal the next chunk (wave-uniform)
+        // the next chunk (wave-uniform): the following one when the waves split rows, else stolen from the counter
         first_chunk = false;
-        uint32_t nx = 0u;
-        if (lane == 0) nx = atomicAdd(&next_chunk, 1u);
-        chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
+        if (rowsplit) {
+            chunk += 1u;
+        } else {
+            uint32_t nx = 0u;
+            if (lane == 0) nx = atomicAdd(&next_chunk, 1u);
+            chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
+        }
     }
     __syncthreads();
 

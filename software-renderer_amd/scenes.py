@@ -435,3 +435,19 @@ def degenerate_mix(width: int = 256, height: int = 128, seed: int = 0x5EED0300, 
     half = (soup.indices.size // 6) * 3
     idx = np.concatenate([soup.indices[:half], nv0 + np.arange(dv.shape[0], dtype=np.int64), soup.indices[half:]])
     return Scene("degenerate_mix", width, height, np.concatenate([soup.vertices, dv]), idx, identity(), flags, {})
+
+
+def occluded_soup(ntri: int = 1_000_000, width: int = 3840, height: int = 2160, z_occluder: float = 0.5,
+                  depth_only: bool = True, tilt: float = 0.0, **kw) -> Scene:
+    """The cfg4 soup behind (and in front of) a screen-filling quad at depth z_occluder (two big triangles, optionally
+    tilted in z): what hierarchical early-z is for — whole tiles whose farthest stored depth is nearer than every
+    fragment of the small triangles that come later in the bin.  z_occluder = 0.5 hides about half of the soup."""
+    sc = cfg4_soup(ntri=ntri, width=width, height=height, depth_only=depth_only, **kw)
+    z0, z1 = z_occluder - tilt, z_occluder + tilt
+    quad = np.array([[-1.2, -1.2, z0], [1.2, -1.2, z0], [1.2, 1.2, z1], [-1.2, -1.2, z0], [1.2, 1.2, z1], [-1.2, 1.2, z1]], np.float32)
+    qv = pack_vertices(quad, np.tile(np.float32([0.2, 0.4, 0.9]), (6, 1)))
+    nv0 = sc.vertices.shape[0]
+    half = (sc.indices.size // 6) * 3
+    idx = np.concatenate([sc.indices[:half], nv0 + np.arange(6, dtype=np.int64), sc.indices[half:]])
+    return Scene("occluded_soup", width, height, np.concatenate([sc.vertices, qv]), idx, sc.transform, sc.flags,
+                 {**sc.meta, "z_occluder": z_occluder})

@@ -184,18 +184,32 @@ def test_bin_overflow_is_repaired_or_reported(swr, oracle):
         same(None, d.array, None, rc_d, "overflow repaired at present_wait")
         assert ctx.timings()["tile_pairs"] > 2 * s.triangles + 65536
         d.free()
-    # (2) an un-waited burst: the earlier overflowing frame was rastered empty -> reported once, bins grown
+    # (2) an un-waited burst of PRESENTED frames: the earlier overflowing frame was rastered empty and copied to the
+    # host like that -> reported once, bins grown, the last frame repaired
+    with swr.Context() as ctx:
+        ctx.scene_upload(s.vertices, s.indices)
+        ctx.target_set(s.width, s.height)
+        d = swr.HostImage((s.height, s.width), np.float32)
+        for _ in range(2):
+            ctx.draw(s.transform, DT | NC)
+            ctx.present(None, d)
+        with pytest.raises(swr.SwrError) as e:
+            ctx.present_wait()
+        assert e.value.code == -8                                             # SWR_ERR_FRAME_DROPPED
+        ctx.present_wait()                                                    # the burst's last frame was redrawn and copied again
+        same(None, d.array, None, rc_d, "last frame of the burst, repaired")
+        ctx.draw(s.transform, DT | NC)
+        ctx.sync()
+        same(None, ctx.read_depth(), None, rc_d, "after the reported drop")
+        d.free()
+    # (2b) the same burst without any present: nobody can have seen the empty frame -> no error, last frame repaired
     with swr.Context() as ctx:
         ctx.scene_upload(s.vertices, s.indices)
         ctx.target_set(s.width, s.height)
         ctx.draw(s.transform, DT | NC)
         ctx.draw(s.transform, DT | NC)
-        with pytest.raises(swr.SwrError) as e:
-            ctx.sync()
-        assert e.value.code == -8                                             # SWR_ERR_FRAME_DROPPED
-        ctx.draw(s.transform, DT | NC)
         ctx.sync()
-        same(None, ctx.read_depth(), None, rc_d, "after the reported drop")
+        same(None, ctx.read_depth(), None, rc_d, "burst without presents")
     # (3) the same through a group and swr_render
     with swr.Context(0, device_count=2) as ctx:
         _, d = ctx.render(s.vertices, s.indices, s.transform, s.width, s.height, DT | NC)

@@ -31,7 +31,7 @@ for name, scene, flags in (("cfg2 torus 6320 tris 1080p painter", S.cfg2_teapot_
         for _ in range(50): ctx.draw(m, flags)
         ctx.sync()
         dt = (time.perf_counter() - t0) / 50
-        ctx.timing_enable(2); ctx.timing_reset()
+        ctx.pipeline_enable(False); ctx.timing_enable(2); ctx.timing_reset()     # stages serialised on one stream
         for _ in range(10): ctx.draw(m, flags)
         sums, n = ctx.timing_totals()
         print(f"{name}: {dt*1e3:.4f} ms/frame = {W*H/dt/1e6:.0f} Mpix/s; stages(ms) " +

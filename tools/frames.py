@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Draw N frames of a named config (for rocprofv3 --kernel-trace --stats): python tools/frames.py cfg5 [N] [band k of n]"""
+import sys
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import swr_amd
+S = swr_amd.scenes
+name = sys.argv[1] if len(sys.argv) > 1 else "cfg4"
+n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+sc = {"cfg4": lambda: S.cfg4_soup(), "cfg5": lambda: S.cfg5_sponza_scale(), "cfg3": lambda: S.cfg3_bunny_scale(),
+      "cfg2": lambda: S.cfg2_teapot_scale(), "cfg4c": lambda: S.cfg4_soup(depth_only=False)}[name]()
+with swr_amd.Context() as ctx:
+    ctx.scene_upload(sc.vertices, sc.indices)
+    r0, r1 = 0, sc.height
+    if len(sys.argv) > 4:
+        r0, r1 = swr_amd.band_rows(sc.height, int(sys.argv[4]), int(sys.argv[3]))
+    ctx.target_set(sc.width, sc.height, r0, r1)
+    for _ in range(n):
+        ctx.draw(sc.transform, sc.flags)
+    ctx.sync()
+    print(name, "rows", r0, r1, ctx.timings())

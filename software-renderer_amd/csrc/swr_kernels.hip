@@ -367,7 +367,9 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
 #ifndef SWR_BIG_AREA
 #define SWR_BIG_AREA (1 << 20)
 #endif
-constexpr int BIG_AREA = SWR_BIG_AREA;   // clipped bbox area above which a triangle is walked by the whole wave (never: the dense path handles any span)
+constexpr int BIG_AREA = SWR_BIG_AREA;
+constexpr int LARGE_AREA = TILE_W * TILE_H / 2;   // clipped bbox area from which a triangle counts as large for its tile ...
+constexpr int LARGE_MAX = 2;                      // ... and goes the cooperative way if the chunk has at most this many   // clipped bbox area above which a triangle is walked by the whole wave (never: the dense path handles any span)
 constexpr uint32_t CLASS_SHIFT = 26;
 constexpr uint32_t CLASS_BIG = 32;
 constexpr int NUM_CLASSES = 33;
@@ -991,7 +993,7 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
         }
         TriState t;
         int ya = 1, yb = 0, bxa = 0, bxb = -1;
-        bool big = false;
+        bool big = false, large = false;
         if (have) {
             int minx, maxx;
             uint32_t prim = prim_pre;
@@ -1030,6 +1032,7 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             // the dense path below needs the exact small-coordinate arithmetic; everything else
             // (huge extents, large clipped area) is walked cooperatively in phase 2
             big = !t.ch.small || maxx - minx >= 16384 || (yb - ya + 1) * (bxb - bxa + 1) > BIG_AREA;
+            large = !big && (yb - ya + 1) * (bxb - bxa + 1) >= LARGE_AREA;
             if (EARLYZ && !first_chunk && !big && ya <= yb && bxa <= bxb) {
                 // Hierarchical z: drop the triangle (for this tile / this wave's rows) when a lower bound of its depth
                 // over every pixel it can cover — its clipped bounding box: spans include pixels OUTSIDE the true
@@ -1061,6 +1064,15 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             }
         }
 
+        // A FEW large triangles among many small ones (a ground plane, a wall, an occluder: at most LARGE_MAX lanes of
+        // the chunk cover half the tile or more) are walked cooperatively too: in the dense phase their lane would
+        // queue QMAXU units per step and hold the whole wave back for 5-6 steps per row (occluded soup: 238 -> 108 us).
+        // When every triangle of the chunk is large the dense phase is the faster one (300 screen-filling triangles:
+        // 177 vs 257 us), so the count decides.
+        {
+            const unsigned long long lm = __ballot(have && large);
+            if (lm != 0ull && __popcll(lm) <= LARGE_MAX) big = big || large;
+        }
         // ---- big or huge-coordinate triangles first, one at a time, walked by the whole wave ----
         // (done before the dense phase so that its per-triangle registers die early)
         unsigned long long bigmask = __ballot(have && big);

@@ -225,7 +225,22 @@ __device__ __forceinline__ float tinv_of(int ax, int ay, int bx, int by, int cx,
     const float m00 = ((float)ax + 0.5f) - cfx, m10 = ((float)ay + 0.5f) - cfy;
     const float m01 = ((float)bx + 0.5f) - cfx, m11 = ((float)by + 0.5f) - cfy;
     const float det = m00 * m11 - m01 * m10;
-    t00 = m11 / det; t01 = -m01 / det; t10 = -m10 / det; t11 = m00 / det;
+    // Four IEEE divisions by the same divisor.  The compiler's f32 division is: scale, rcp, one Newton step on the
+    // reciprocal, quotient, two residual corrections (fma), unscale, fix-up of the special cases.  Here the operands
+    // are integer-valued floats (|n| < 2^31, |det| < 2^62 for coordinates below 2^30): nothing needs scaling, no
+    // intermediate leaves the normal range, and the reciprocal refinement is shared between the four quotients.
+    // v_div_fixup restores what the refinement loses: the sign of a zero quotient (-0 / det), x / 0 = +-inf and
+    // 0 / 0 = NaN of a degenerate triangle (det == 0), NaN propagation.  Correctly rounded, bit for bit what '/' gives
+    // (the oracle divides plainly; every parity test goes through here).
+    const float rc0 = __builtin_amdgcn_rcpf(det);
+    const float rcp = __builtin_fmaf(__builtin_fmaf(-det, rc0, 1.0f), rc0, rc0);
+    auto div_exact = [&](float n) {
+        const float q0 = n * rcp;
+        const float q1 = __builtin_fmaf(__builtin_fmaf(-det, q0, n), rcp, q0);
+        const float q2 = __builtin_fmaf(__builtin_fmaf(-det, q1, n), rcp, q1);
+        return __builtin_amdgcn_div_fixupf(q2, det, n);
+    };
+    t00 = div_exact(m11); t01 = div_exact(-m01); t10 = div_exact(-m10); t11 = div_exact(m00);
     return det;
 }
 
@@ -897,8 +912,10 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
     constexpr int UNIT = SWR_UNIT;    // consecutive pixels of one span handled by one lane of a dense step
 
     __shared__ uint32_t next_chunk;           // work-stealing cursor over the chunks of the sorted bin
-    __shared__ float4 tabA[RASTER_THREADS];   // per triangle of the batch: t00, t01, t10, t11
-    __shared__ float4 tabB[RASTER_THREADS];   //                            za, zb, zc, (C.x - X0) | (C.y - Y0) << 16
+    __shared__ float4 tabAB[2 * RASTER_THREADS];
+    float4* const tabA = tabAB;                    // per triangle of the batch: t00, t01, t10, t11
+    float4* const tabB = tabAB + RASTER_THREADS;   //                            za, zb, zc, (C.x - X0) | (C.y - Y0) << 16
+    uint32_t* const slots = reinterpret_cast<uint32_t*>(tabAB);   // resolve only (see below)
     __shared__ uint32_t tabP[RASTER_THREADS]; //                            original primitive index (the key's low word)
     // per wave: ring of 4-pixel work units waiting for a lane.  entry = owner lane | xl0 << 6 | yl << 12 | (pixels-1) << 17
     constexpr int QMAXU = 3;                  // units one lane may queue per row step (wider spans take another step)
@@ -906,6 +923,8 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
     static_assert(63 + 64 * QMAXU <= QCAP && (QCAP & (QCAP - 1)) == 0, "unit ring size");
     __shared__ uint32_t queue[RASTER_THREADS / 64][QCAP];
     __shared__ unsigned long long keys[TILE_W * TILE_H];
+    // after the last chunk the per-triangle tables are dead: the resolve keeps the winners' stream slots there
+    static_assert(sizeof(float4) * 2 * RASTER_THREADS >= sizeof(uint32_t) * TILE_W * TILE_H, "slots alias tabA + tabB");
 #ifndef SWR_EARLYZ
 #define SWR_EARLYZ 0   // measured (profiles/r02/earlyz_ab.txt): costs 5 % everywhere, gains nothing — see DESIGN.md §6
 #endif
@@ -1337,6 +1356,22 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
     const bool want_color = a.color != nullptr;
     const int W = a.tg.width;
     const bool vec_ok = (W & 3) == 0;
+    // Colour frames: the stream slots of ALL this thread's winners first (original index -> slot is a gather from a
+    // 4 MB table; the keys hold the original index because it decides depth ties) — 8 independent loads in flight
+    // instead of 4 + 4 behind each other — written back into the low words of the keys, which have done their job.
+    static_assert(TILE_W * TILE_H / 4 == 2 * RASTER_THREADS, "two 4-pixel groups per thread");
+    if (want_color && a.reordered && VAR != 8 && VAR != 10 && VAR != 11) {
+        uint32_t sl[8];
+#pragma unroll
+        for (int g = 0; g < 8; g++) {
+            const int p = (tid + (g >> 2) * RASTER_THREADS) * 4 + (g & 3);
+            const unsigned long long key = keys[p];
+            const uint32_t prim = ZTEST ? (uint32_t)key : 0xFFFFFFFFu - (uint32_t)key;
+            sl[g] = (uint32_t)(key >> 32) < KEY_LIVE_BELOW ? a.inv[prim] : 0u;
+        }
+#pragma unroll
+        for (int g = 0; g < 8; g++) slots[(tid + (g >> 2) * RASTER_THREADS) * 4 + (g & 3)] = sl[g];
+    }
     for (int i = tid; VAR != 8 && VAR != 10 && VAR != 11 && i < TILE_W * TILE_H / 4; i += RASTER_THREADS) {
         const int ly = (i * 4) / TILE_W, lx = (i * 4) % TILE_W;
         const int y = Y0 + ly, x = X0 + lx;
@@ -1357,8 +1392,7 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
         for (int k = 0; k < 4; k++) {
             key4[k] = keys[ly * TILE_W + lx + k];
             const uint32_t prim = ZTEST ? (uint32_t)key4[k] : 0xFFFFFFFFu - (uint32_t)key4[k];
-            slot4[k] = prim;
-            if (want_color && a.reordered && (uint32_t)(key4[k] >> 32) < KEY_LIVE_BELOW) slot4[k] = a.inv[prim];
+            slot4[k] = (want_color && a.reordered) ? slots[ly * TILE_W + lx + k] : prim;
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {

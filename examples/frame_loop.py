@@ -10,7 +10,9 @@ and advances `time += 1/60` (App.swift:155-157).  Here the mesh stays resident o
 
 The demo mesh is a UV sphere standing in for ModelIO's `MDLMesh(sphereWithExtent: 0.4, segments: 13x13,
 inwardNormals: true)` (App.swift:124) with colour = |normal| (App.swift:133).  `--obj` loads a
-Wavefront OBJ instead (positions + optional normals; faces are fan-triangulated).
+Wavefront OBJ instead (positions + optional normals; faces are fan-triangulated); `--ply` a Stanford PLY
+(ascii or binary_little_endian; x y z, optional nx ny nz or red green blue; faces fan-triangulated) — the format
+the Stanford bunny ships in.  Neither format is part of the reference (its only mesh is the ModelIO sphere).
 """
 import argparse
 import math
@@ -86,6 +88,118 @@ def load_obj(path: str):
             np.array(idx, dtype=np.int64))
 
 
+_PLY_TYPES = {"char": "i1", "int8": "i1", "uchar": "u1", "uint8": "u1", "short": "i2", "int16": "i2", "ushort": "u2",
+              "uint16": "u2", "int": "i4", "int32": "i4", "uint": "u4", "uint32": "u4", "float": "f4", "float32": "f4",
+              "double": "f8", "float64": "f8"}
+
+
+def load_ply(path: str):
+    """Minimal Stanford PLY reader (ascii 1.0 / binary_little_endian 1.0): element vertex with x y z and optional
+    nx ny nz (colour = |normal|, as the app does, App.swift:133) or red green blue (uchar 0..255 or float 0..1);
+    element face with one list property (vertex_indices), fan-triangulated.  Other elements / properties are skipped."""
+    with open(path, "rb") as f:
+        if f.readline().strip() != b"ply":
+            raise ValueError("not a PLY file")
+        fmt, elements = None, []
+        while True:
+            t = f.readline().decode("ascii", "replace").split()
+            if not t:
+                continue
+            if t[0] == "format":
+                fmt = t[1]
+            elif t[0] == "element":
+                elements.append({"name": t[1], "count": int(t[2]), "props": []})
+            elif t[0] == "property":
+                if t[1] == "list":
+                    elements[-1]["props"].append(("list", t[2], t[3], t[4]))
+                else:
+                    elements[-1]["props"].append(("scalar", t[1], t[2]))
+            elif t[0] == "end_header":
+                break
+        if fmt not in ("ascii", "binary_little_endian"):
+            raise ValueError(f"unsupported PLY format {fmt}")
+        verts, faces = None, []
+        if fmt == "ascii":
+            tokens = f.read().split()
+            pos = 0
+        for el in elements:
+            scalars = [p for p in el["props"] if p[0] == "scalar"]
+            lists = [p for p in el["props"] if p[0] == "list"]
+            if el["name"] == "vertex" and not lists:
+                names = [p[2] for p in scalars]
+                if fmt == "ascii":
+                    n = len(names) * el["count"]
+                    arr = np.array(tokens[pos:pos + n], dtype=np.float64).reshape(el["count"], len(names))
+                    pos += n
+                    cols = {nm: arr[:, k] for k, nm in enumerate(names)}
+                    isint = {p[2]: _PLY_TYPES[p[1]][0] in "iu" for p in scalars}
+                else:
+                    dt = np.dtype([(p[2], "<" + _PLY_TYPES[p[1]]) for p in scalars])
+                    arr = np.frombuffer(f.read(dt.itemsize * el["count"]), dtype=dt)
+                    cols = {nm: arr[nm].astype(np.float64) for nm in names}
+                    isint = {p[2]: _PLY_TYPES[p[1]][0] in "iu" for p in scalars}
+                xyz = np.stack([cols["x"], cols["y"], cols["z"]], -1).astype(np.float32)
+                if all(k in cols for k in ("red", "green", "blue")):
+                    rgb = np.stack([cols["red"], cols["green"], cols["blue"]], -1)
+                    if isint["red"]:
+                        rgb = rgb / 255.0
+                elif all(k in cols for k in ("nx", "ny", "nz")):
+                    rgb = np.abs(np.stack([cols["nx"], cols["ny"], cols["nz"]], -1))
+                else:
+                    rgb = np.full(xyz.shape, 0.577)
+                verts = (xyz, rgb.astype(np.float32))
+            else:                                   # faces (or anything else: parsed to stay in sync, kept only for "face")
+                for _ in range(el["count"]):
+                    row_lists = []
+                    for p in el["props"]:
+                        if p[0] == "scalar":
+                            if fmt == "ascii":
+                                pos += 1
+                            else:
+                                f.read(np.dtype(_PLY_TYPES[p[1]]).itemsize)
+                        else:
+                            if fmt == "ascii":
+                                n = int(tokens[pos]); pos += 1
+                                row_lists.append([int(x) for x in tokens[pos:pos + n]]); pos += n
+                            else:
+                                n = int(np.frombuffer(f.read(np.dtype(_PLY_TYPES[p[1]]).itemsize), dtype="<" + _PLY_TYPES[p[1]])[0])
+                                dt = np.dtype("<" + _PLY_TYPES[p[2]])
+                                row_lists.append(np.frombuffer(f.read(dt.itemsize * n), dtype=dt).astype(np.int64).tolist())
+                    if el["name"] == "face" and row_lists:
+                        face = row_lists[0]
+                        for k in range(1, len(face) - 1):
+                            faces += [face[0], face[k], face[k + 1]]
+        if verts is None:
+            raise ValueError("PLY file without a vertex element")
+    return S.pack_vertices(verts[0], verts[1]), np.array(faces, dtype=np.int64)
+
+
+def write_ply(path: str, vertices: np.ndarray, indices: np.ndarray, binary: bool = True):
+    """Writes the mesh as PLY (x y z + float red green blue; triangles) — the inverse of load_ply, for round trips."""
+    v = np.asarray(vertices, dtype=np.float32).reshape(-1, 8)
+    tri = np.asarray(indices, dtype=np.int64).reshape(-1, 3)
+    hdr = ("ply\nformat %s 1.0\ncomment written by examples/frame_loop.py\nelement vertex %d\nproperty float x\nproperty float y\n"
+           "property float z\nproperty float red\nproperty float green\nproperty float blue\nelement face %d\n"
+           "property list uchar int vertex_indices\nend_header\n") % ("binary_little_endian" if binary else "ascii", v.shape[0], tri.shape[0])
+    with open(path, "wb") as f:
+        f.write(hdr.encode("ascii"))
+        if binary:
+            f.write(np.ascontiguousarray(v[:, [0, 1, 2, 4, 5, 6]], dtype="<f4").tobytes())
+            rec = np.zeros(tri.shape[0], dtype=[("n", "u1"), ("i", "<i4", 3)])
+            rec["n"] = 3
+            rec["i"] = tri
+            f.write(rec.tobytes())
+        else:
+            for row in v[:, [0, 1, 2, 4, 5, 6]]:
+                f.write((" ".join(repr(float(x)) for x in row) + "\n").encode("ascii"))
+            for t in tri:
+                f.write(("3 %d %d %d\n" % tuple(int(x) for x in t)).encode("ascii"))
+
+
+def load_mesh(path: str):
+    return load_ply(path) if path.lower().endswith(".ply") else load_obj(path)
+
+
 def write_ppm(path: str, bgra: np.ndarray):
     h, w, _ = bgra.shape
     with open(path, "wb") as f:
@@ -96,7 +210,7 @@ def write_ppm(path: str, bgra: np.ndarray):
 def run(frames: int, size: int, out: str | None, obj: str | None = None, depth_test: bool = False,
         time0: float = 0.0):
     """Returns the list of (colour, depth) frames; writes PPMs when `out` is given."""
-    vertices, indices = load_obj(obj) if obj else sphere_mesh()
+    vertices, indices = load_mesh(obj) if obj else sphere_mesh()
     flags = S.FLAG_DEPTH_TEST if depth_test else 0
     results = []
     with swr_amd.Context() as ctx:
@@ -120,9 +234,10 @@ if __name__ == "__main__":
     ap.add_argument("--frames", type=int, default=4)
     ap.add_argument("--size", type=int, default=512)    # the app renders 512x512 (App.swift:52-53)
     ap.add_argument("--out", default=None)
-    ap.add_argument("--obj", default=None)
+    ap.add_argument("--obj", default=None, help="Wavefront OBJ mesh")
+    ap.add_argument("--ply", default=None, help="Stanford PLY mesh (ascii or binary little endian)")
     ap.add_argument("--depth-test", action="store_true")
     a = ap.parse_args()
-    _, idx, res = run(a.frames, a.size, a.out, a.obj, a.depth_test)
+    _, idx, res = run(a.frames, a.size, a.out, a.ply or a.obj, a.depth_test)
     cov = [(c[..., 3] == 255).mean() for c, _, _ in res]
     print(f"{a.frames} frames, {idx.size // 3} triangles, coverage per frame: {[round(float(x), 4) for x in cov]}")

@@ -140,8 +140,9 @@ struct RenderPass {
 namespace detail {
 class Context {
 public:
-    Context() {
-        swr_config cfg{-1, 0};
+    // deviceCount > 1: one context drives that many tile-row bands, on as many GPUs as are visible (swr_config.device_count)
+    explicit Context(uint32_t deviceCount = 0) {
+        swr_config cfg{deviceCount > 1 ? 0 : -1, deviceCount};
         int rc = swr_context_create(&cfg, &ctx_);
         if (rc) throw RenderError(rc, swr_last_error(nullptr));
     }
@@ -206,6 +207,10 @@ private:
 // restored from Renderer.swift:257-261.  depthTest = false gives Renderer's output.
 class GpuRenderer {
 public:
+    GpuRenderer() = default;
+    // One renderer, N GPUs: the framebuffer is cut into N tile-row bands and every band is copied straight into its rows
+    // of RenderPass.colorBuffer / .depthBuffer (the reference has exactly one synchronous draw call, GpuRenderer.swift:35).
+    explicit GpuRenderer(uint32_t deviceCount) : ctx_(deviceCount) {}
     bool depthTest = true;
     // true: the Metal kernels' own rules (round() snap, ROI threads + inside test, UNORM rounding,
     // ROI-min == 0 skip; Shaders.metal:57-167, GpuRenderer.swift:122-124) instead of the CPU renderer's

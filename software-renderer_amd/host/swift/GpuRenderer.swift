@@ -20,8 +20,10 @@ final class GpuRenderer {
     var material: swr_material? = nil
     var texture: Image<Pixel>? = nil
 
-    init() {
-        var cfg = swr_config(device: -1, reserved: 0)
+    /// deviceCount > 1: ONE renderer drives that many GPUs — the framebuffer is cut into tile-row bands, every band is
+    /// copied straight into its rows of the caller's image (swr_config.device_count; include/swr.h).
+    init(deviceCount: UInt32 = 0) {
+        var cfg = swr_config(device: deviceCount > 1 ? 0 : -1, device_count: deviceCount)
         let rc = swr_context_create(&cfg, &ctx)
         precondition(rc == SWR_OK, String(cString: swr_last_error(nil)))   // original: try! (GpuRenderer.swift:20-31)
     }

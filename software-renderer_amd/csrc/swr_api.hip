@@ -185,6 +185,16 @@ struct swr_context {
     bool frame_presented[PAIR_RING] = {};   // was frame f copied to the host (swr_present)?  Only then can an overflow be seen
     uint32_t* h_misc = nullptr;
     uint64_t frames_checked = 0;        // frames [frames_checked, frame_no) have not had their pair total looked at
+    // Two host threads per context: every frame is ~9 HIP calls (3.5 us each); the binning stream's share (slot wait,
+    // three or four launches, event record) is enqueued by `bin_worker` while the caller's thread enqueues the raster
+    // stream's share (event wait, launches, event record) of the PREVIOUS frame — a thin band or a small scene is
+    // bound by the host's enqueue rate, not by the GPU.
+    Worker* bin_worker = nullptr;
+    std::atomic<uint64_t> bin_enqueued{0};      // frames whose binning (incl. the bin_done record) is on the binning stream
+    std::atomic<uint64_t> ras_enqueued{0};      // frames whose raster (incl. the ras_done record) is on the raster stream
+    std::atomic<int> bin_error{0};
+    uint64_t posted = 0;                        // frames whose binning share has been handed to the helper (or run inline)
+    struct RasJob { DeviceFrame f; hipEvent_t ev3 = nullptr, ev4 = nullptr; int si = 0; bool sort_here = false; int fb = 0; } ras_job[NSLOT];
     // last draw (for the overflow redo and for swr_render)
     float last_m[16]{};
     uint32_t last_flags = 0;
@@ -263,7 +273,11 @@ int ensure_capacity(swr_context* c, uint32_t cap) {
     return SWR_OK;
 }
 
+int flush_raster(swr_context* c, uint64_t upto_frame_count);
+
 int sync_streams(swr_context* c) {
+    int rc = flush_raster(c, c->frame_no);      // everything drawn so far is on the streams
+    if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->bin_stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
     return SWR_OK;
@@ -365,7 +379,11 @@ int enqueue_frame(swr_context* c) {
     c->fb_last = c->fb_cur;
     if (tiles_of(c->tg) == 0) {
         // an empty band (a group with more sub-contexts than tile rows hands these out): nothing to bin, raster or copy
+        int rc = flush_raster(c, c->frame_no);
+        if (rc) return rc;
         pair_word(c, c->frame_no++) = 0;
+        c->posted = c->frame_no;
+        c->bin_enqueued.store(c->frame_no); c->ras_enqueued.store(c->frame_no);
         c->draw_pending = true;
         return SWR_OK;
     }
@@ -379,6 +397,8 @@ int enqueue_frame(swr_context* c) {
         if ((rc = wait_for_copies_of(c, c->fb_cur, c->stream))) return rc;
         launch_points_or_lines(f, c->last_prim, c->stream);
         HIP_TRY(c, hipGetLastError());
+        c->posted = c->frame_no;
+        c->bin_enqueued.store(c->frame_no); c->ras_enqueued.store(c->frame_no);
         c->draw_pending = true;
         return SWR_OK;
     }
@@ -386,7 +406,6 @@ int enqueue_frame(swr_context* c) {
     c->frame_presented[frame % swr_context::PAIR_RING] = false;
     const int si = (int)(frame % swr_context::NSLOT);
     c->last_slot = si;
-    swr_context::Slot& sl = c->slot[si];
     DeviceFrame f = make_frame(c, si, frame, c->last_m, c->last_flags);
     hipEvent_t* ev = nullptr;
     if (c->timing >= 2 || (c->timing == 1 && (c->frame_no % (uint64_t)c->timing_every) == 0)) {
@@ -401,23 +420,6 @@ int enqueue_frame(swr_context* c) {
     }
     hipStream_t sb = c->bin_stream, sr = c->stream;
     c->hp_lap(0);
-    // this slot's buffers are free again once the raster of NSLOT frames ago has read them
-    if (sl.ras_recorded && sb != sr) HIP_TRY(c, hipStreamWaitEvent(sb, sl.ras_done, 0));
-    c->hp_lap(1);
-    if (!f.plan.use_lds || f.ntri <= 0) {
-        // global-atomic fallback: counters must start at zero.  Empty scene: no binning kernel
-        // runs at all, so the tile table (counts, starts, counters) is simply zeroed.
-        if (f.ntri <= 0) { int rc = sync_streams(c); if (rc) return rc; pair_word(c, frame) = 0; }
-        const size_t zero_bytes = (size_t)(CNT_WORDS + 3 * tiles_of(c->tg) + 1) * 4;
-        HIP_TRY(c, hipMemsetAsync(sl.tilebuf.p, 0, zero_bytes, sb));
-    }
-    const bool all = c->timing >= 2;
-    if (ev && all) HIP_TRY(c, hipEventRecord(ev[0], sb));
-    launch_setup_bin(f, sb);
-    if (ev && all) HIP_TRY(c, hipEventRecord(ev[1], sb));
-    launch_scan(f, sb);
-    if (ev && all) HIP_TRY(c, hipEventRecord(ev[2], sb));
-    launch_fill(f, sb);
     // Where k_sort_bins runs.  On the binning stream it is part of the chain that runs ahead of the raster; on
     // the raster stream (right before k_raster) the binning stream is free one kernel earlier.  Alternating A/B on
     // one box (tools/ab_sort_stream.py, tools/bt_bands.sh; untimed frames of cfg4, us per frame):
@@ -427,25 +429,85 @@ int enqueue_frame(swr_context* c) {
     static const int sort_stream_mode = getenv("SWR_SORT_STREAM") ? atoi(getenv("SWR_SORT_STREAM")) : -1;
     const bool sort_on_raster_stream = sort_stream_mode >= 0 ? sort_stream_mode == 1
                                                             : (sb != sr && f.ntri >= 200000 && tiles_of(c->tg) < 3000);
-    if (!sort_on_raster_stream) launch_sort_bins(f, sb);
-    c->hp_lap(2);
-    if (sb != sr) {
-        HIP_TRY(c, hipEventRecord(sl.bin_done, sb));
-        HIP_TRY(c, hipStreamWaitEvent(sr, sl.bin_done, 0));
-    }
-    c->hp_lap(3);
-    { int rc = wait_for_copies_of(c, c->fb_cur, sr); if (rc) return rc; }
-    if (sort_on_raster_stream) launch_sort_bins(f, sr);
-    if (ev) HIP_TRY(c, hipEventRecord(ev[3], sr));
-    launch_raster(f, sr);
-    if (ev) HIP_TRY(c, hipEventRecord(ev[4], sr));
-    c->hp_lap(4);
-    if (sb != sr) { HIP_TRY(c, hipEventRecord(sl.ras_done, sr)); sl.ras_recorded = true; }
-    c->hp_lap(5);
-    c->hp_frames++;
-    HIP_TRY(c, hipGetLastError());
+    const bool all = c->timing >= 2;
+    if (f.ntri <= 0) { int rc = sync_streams(c); if (rc) return rc; pair_word(c, frame) = 0; }
+    const bool zero_tables = !f.plan.use_lds || f.ntri <= 0;
+    const size_t zero_bytes = (size_t)(CNT_WORDS + 3 * tiles_of(c->tg) + 1) * 4;
+    hipEvent_t e0 = (ev && all) ? ev[0] : nullptr, e1 = (ev && all) ? ev[1] : nullptr, e2 = (ev && all) ? ev[2] : nullptr;
+    // ---- the binning stream's share of the frame ----
+    auto bin_share = [c, f, si, sb, sr, frame, zero_tables, zero_bytes, e0, e1, e2, sort_on_raster_stream]() -> int {
+        swr_context::Slot& sl = c->slot[si];
+        if (sb != sr && frame >= (uint64_t)swr_context::NSLOT) {
+            // this slot's buffers are free again once the raster of NSLOT frames ago has read them: its ras_done must
+            // have been RECORDED (by the caller's thread) before the wait on it is enqueued
+            while (c->ras_enqueued.load(std::memory_order_acquire) + (uint64_t)swr_context::NSLOT <= frame) __builtin_ia32_pause();
+            if (sl.ras_recorded) HIP_TRY(c, hipStreamWaitEvent(sb, sl.ras_done, 0));
+        }
+        // global-atomic fallback: counters must start at zero.  Empty scene: no binning kernel runs at all, so the
+        // tile table (counts, starts, counters) is simply zeroed.
+        if (zero_tables) HIP_TRY(c, hipMemsetAsync(sl.tilebuf.p, 0, zero_bytes, sb));
+        if (e0) HIP_TRY(c, hipEventRecord(e0, sb));
+        launch_setup_bin(f, sb);
+        if (e1) HIP_TRY(c, hipEventRecord(e1, sb));
+        launch_scan(f, sb);
+        if (e2) HIP_TRY(c, hipEventRecord(e2, sb));
+        launch_fill(f, sb);
+        if (!sort_on_raster_stream) launch_sort_bins(f, sb);
+        if (sb != sr) HIP_TRY(c, hipEventRecord(sl.bin_done, sb));
+        HIP_TRY(c, hipGetLastError());
+        return SWR_OK;
+    };
+    swr_context::RasJob& rj = c->ras_job[si];
+    rj.f = f; rj.ev3 = ev ? ev[3] : nullptr; rj.ev4 = ev ? ev[4] : nullptr; rj.si = si; rj.sort_here = sort_on_raster_stream;
+    rj.fb = c->fb_cur;
     c->draw_pending = true;   // the pair total lands in the frame's pinned word (written by the scan)
-    return SWR_OK;
+    c->posted = frame + 1;
+    if (sb != sr && c->bin_worker) {
+        // two threads: the helper enqueues this frame's binning while this thread enqueues the previous frame's raster
+        c->bin_worker->post([c, bin_share, frame]() -> int {
+            const int rc = bin_share();
+            if (rc) c->bin_error.store(rc, std::memory_order_relaxed);
+            c->bin_enqueued.store(frame + 1, std::memory_order_release);
+            return rc;
+        });
+        c->hp_lap(2);
+        return flush_raster(c, frame);            // frames < frame; this one follows with the next draw / sync / present
+    }
+    { int rc = bin_share(); if (rc) return rc; }
+    c->bin_enqueued.store(frame + 1, std::memory_order_release);
+    c->hp_lap(2);
+    return flush_raster(c, frame + 1);
+}
+
+// The raster stream's share of every frame below `upto` that has not been enqueued yet.
+int flush_raster(swr_context* c, uint64_t upto) {
+    for (;;) {
+        const uint64_t g = c->ras_enqueued.load(std::memory_order_relaxed);
+        if (g >= upto || g >= c->posted) return SWR_OK;
+        while (c->bin_enqueued.load(std::memory_order_acquire) <= g) __builtin_ia32_pause();
+        if (c->bin_error.load(std::memory_order_relaxed)) {
+            const int rc = c->bin_error.exchange(0);
+            c->ras_enqueued.store(c->posted, std::memory_order_release);
+            return rc ? rc : SWR_ERR_HIP;          // c->err was set by the helper
+        }
+        swr_context::RasJob& rj = c->ras_job[g % swr_context::NSLOT];
+        swr_context::Slot& sl = c->slot[rj.si];
+        hipStream_t sb = c->bin_stream, sr = c->stream;
+        c->hp_begin();
+        if (sb != sr) HIP_TRY(c, hipStreamWaitEvent(sr, sl.bin_done, 0));
+        c->hp_lap(3);
+        { int rc = wait_for_copies_of(c, rj.fb, sr); if (rc) return rc; }
+        if (rj.sort_here) launch_sort_bins(rj.f, sr);
+        if (rj.ev3) HIP_TRY(c, hipEventRecord(rj.ev3, sr));
+        launch_raster(rj.f, sr);
+        if (rj.ev4) HIP_TRY(c, hipEventRecord(rj.ev4, sr));
+        c->hp_lap(4);
+        if (sb != sr) { HIP_TRY(c, hipEventRecord(sl.ras_done, sr)); sl.ras_recorded = true; }
+        c->hp_lap(5);
+        c->hp_frames++;
+        HIP_TRY(c, hipGetLastError());
+        c->ras_enqueued.store(g + 1, std::memory_order_release);
+    }
 }
 
 // Is `p` page-locked memory HIP knows (hipHostMalloc / hipHostRegister)?  Then hipMemcpyAsync into it is a true
@@ -699,8 +761,9 @@ int single_draw(swr_context* c, const float transform[16], uint32_t flags, int32
 int enqueue_present(swr_context* c, void* color_full, float* depth_full) {
     const int fb = c->fb_last;
     if (tiles_of(c->tg) == 0) return SWR_OK;
+    int rc = flush_raster(c, c->frame_no);          // the frame being presented must be on the raster stream
+    if (rc) return rc;
     HIP_TRY(c, hipEventRecord(c->frame_done[fb], c->stream));
-    int rc;
     if (color_full && !(c->last_flags & SWR_FLAG_NO_COLOR) && (rc = copy_band(c, fb, 0, color_full))) return rc;
     if (depth_full && (rc = copy_band(c, fb, 1, depth_full))) return rc;
     c->fb_cur = fb ^ 1;     // the next frame renders into the other framebuffer while this one is being copied
@@ -801,6 +864,7 @@ int single_read(swr_context* c, int img, void* dst) {
 
 void destroy_single(swr_context* c) {
     hipSetDevice(c->device);
+    if (c->bin_worker) { c->bin_worker->drain(); c->bin_worker->stop(); delete c->bin_worker; c->bin_worker = nullptr; }
     if (c->bin_stream) hipStreamSynchronize(c->bin_stream);
     if (c->stream) hipStreamSynchronize(c->stream);
     for (int i = 0; i < 2; i++) if (c->copy_stream[i]) hipStreamSynchronize(c->copy_stream[i]);
@@ -864,6 +928,9 @@ int create_single(int dev, swr_context** out) {
             // no difference to how the two queues share the CUs on this platform
             if (hipStreamCreateWithFlags(&c->bin_stream, hipStreamNonBlocking) != hipSuccess) c->bin_stream = c->stream;
             else c->bin_stream_own = c->bin_stream;
+            // SWR_HOST_THREADS=1: enqueue everything from the caller's thread (no helper)
+            const char* ht = getenv("SWR_HOST_THREADS");
+            if (c->bin_stream_own && !(ht && ht[0] == '1')) { c->bin_worker = new Worker(); c->bin_worker->start(dev); }
         }
         for (auto& sl : c->slot) {
             hipEventCreateWithFlags(&sl.bin_done, hipEventDisableTiming);

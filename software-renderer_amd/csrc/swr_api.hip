@@ -190,11 +190,19 @@ struct swr_context {
     // stream's share (event wait, launches, event record) of the PREVIOUS frame — a thin band or a small scene is
     // bound by the host's enqueue rate, not by the GPU.
     Worker* bin_worker = nullptr;
+    // ... and a third one for the raster stream's share, for a different reason: a cross-stream hipStreamWaitEvent in
+    // front of a kernel costs that kernel ~10 us after its predecessor on the queue has ended, even when the event
+    // completed long before (profiles/r02/gaps_pipelined_before.txt) — a wait that is never enqueued costs nothing.
+    // `ras_worker` polls hipEventQuery(bin_done) of the frame and only then enqueues k_raster, with no wait in front
+    // (and `bin_worker` does the same with ras_done before it re-uses a working set).  swr_draw / swr_present only post.
+    // SWR_EVENT_WAITS=1: the caller's thread enqueues the raster share behind event waits (round-2 first half).
+    Worker* ras_worker = nullptr;
     std::atomic<uint64_t> bin_enqueued{0};      // frames whose binning (incl. the bin_done record) is on the binning stream
     std::atomic<uint64_t> ras_enqueued{0};      // frames whose raster (incl. the ras_done record) is on the raster stream
     std::atomic<int> bin_error{0};
     uint64_t posted = 0;                        // frames whose binning share has been handed to the helper (or run inline)
-    struct RasJob { DeviceFrame f; hipEvent_t ev3 = nullptr, ev4 = nullptr; int si = 0; bool sort_here = false; int fb = 0; } ras_job[NSLOT];
+    static constexpr int RAS_RING = 64;          // frames whose raster share may be waiting for ras_worker; swr_draw blocks beyond that
+    struct RasJob { DeviceFrame f; hipEvent_t ev3 = nullptr, ev4 = nullptr; int si = 0; bool sort_here = false; int fb = 0; } ras_job[RAS_RING];
     // last draw (for the overflow redo and for swr_render)
     float last_m[16]{};
     uint32_t last_flags = 0;
@@ -220,6 +228,14 @@ struct swr_context {
     double hp_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t hp_frames = 0;
     std::chrono::steady_clock::time_point hp_last;
+    std::chrono::steady_clock::time_point hp_last_r;    // the raster share's own clock (it may run on ras_worker)
+    void hp_begin_r() { if (hp_on) hp_last_r = std::chrono::steady_clock::now(); }
+    void hp_lap_r(int k) {
+        if (!hp_on) return;
+        const auto now = std::chrono::steady_clock::now();
+        hp_t[k] += std::chrono::duration<double, std::micro>(now - hp_last_r).count();
+        hp_last_r = now;
+    }
     void hp_begin() { if (hp_on) hp_last = std::chrono::steady_clock::now(); }
     void hp_lap(int k) {
         if (!hp_on) return;
@@ -274,6 +290,19 @@ int ensure_capacity(swr_context* c, uint32_t cap) {
 }
 
 int flush_raster(swr_context* c, uint64_t upto_frame_count);
+int enqueue_raster_shares(swr_context* c, uint64_t upto_frame_count);
+
+// hipEventQuery until the event has completed (host-paced ordering: see swr_context::ras_worker)
+int poll_event(swr_context* c, hipEvent_t ev) {
+    for (unsigned spins = 0;;) {
+        const hipError_t e = hipEventQuery(ev);
+        if (e == hipSuccess) return SWR_OK;
+        if (e != hipErrorNotReady) { HIP_TRY(c, e); }
+        (void)hipGetLastError();                  // hipErrorNotReady is sticky in hipGetLastError
+        if (++spins > 20000) std::this_thread::yield();   // more spinning threads than cores (many bands on one box)
+        else for (int i = 0; i < 8; i++) __builtin_ia32_pause();
+    }
+}
 
 int sync_streams(swr_context* c) {
     int rc = flush_raster(c, c->frame_no);      // everything drawn so far is on the streams
@@ -284,6 +313,7 @@ int sync_streams(swr_context* c) {
 }
 
 int sync_copies(swr_context* c) {
+    if (c->ras_worker) { const int rc = c->ras_worker->drain(); if (rc) return rc; }   // posted swr_present copies
     HIP_TRY(c, hipStreamSynchronize(c->copy_stream[0]));
     HIP_TRY(c, hipStreamSynchronize(c->copy_stream[1]));
     return SWR_OK;
@@ -440,8 +470,12 @@ int enqueue_frame(swr_context* c) {
         if (sb != sr && frame >= (uint64_t)swr_context::NSLOT) {
             // this slot's buffers are free again once the raster of NSLOT frames ago has read them: its ras_done must
             // have been RECORDED (by the caller's thread) before the wait on it is enqueued
-            while (c->ras_enqueued.load(std::memory_order_acquire) + (uint64_t)swr_context::NSLOT <= frame) __builtin_ia32_pause();
-            if (sl.ras_recorded) HIP_TRY(c, hipStreamWaitEvent(sb, sl.ras_done, 0));
+            for (unsigned spins = 0; c->ras_enqueued.load(std::memory_order_acquire) + (uint64_t)swr_context::NSLOT <= frame;)
+                if (++spins > 100000) std::this_thread::yield(); else __builtin_ia32_pause();
+            if (sl.ras_recorded) {
+                if (c->ras_worker) { const int rc = poll_event(c, sl.ras_done); if (rc) return rc; }
+                else HIP_TRY(c, hipStreamWaitEvent(sb, sl.ras_done, 0));
+            }
         }
         // global-atomic fallback: counters must start at zero.  Empty scene: no binning kernel runs at all, so the
         // tile table (counts, starts, counters) is simply zeroed.
@@ -457,7 +491,8 @@ int enqueue_frame(swr_context* c) {
         HIP_TRY(c, hipGetLastError());
         return SWR_OK;
     };
-    swr_context::RasJob& rj = c->ras_job[si];
+    while (c->ras_enqueued.load(std::memory_order_acquire) + (uint64_t)swr_context::RAS_RING <= frame) std::this_thread::yield();
+    swr_context::RasJob& rj = c->ras_job[frame % swr_context::RAS_RING];
     rj.f = f; rj.ev3 = ev ? ev[3] : nullptr; rj.ev4 = ev ? ev[4] : nullptr; rj.si = si; rj.sort_here = sort_on_raster_stream;
     rj.fb = c->fb_cur;
     c->draw_pending = true;   // the pair total lands in the frame's pinned word (written by the scan)
@@ -471,6 +506,10 @@ int enqueue_frame(swr_context* c) {
             return rc;
         });
         c->hp_lap(2);
+        if (c->ras_worker) {
+            c->ras_worker->post([c, frame]() -> int { return enqueue_raster_shares(c, frame + 1); });
+            return SWR_OK;
+        }
         return flush_raster(c, frame);            // frames < frame; this one follows with the next draw / sync / present
     }
     { int rc = bin_share(); if (rc) return rc; }
@@ -479,31 +518,44 @@ int enqueue_frame(swr_context* c) {
     return flush_raster(c, frame + 1);
 }
 
-// The raster stream's share of every frame below `upto` that has not been enqueued yet.
+// Every frame below `upto` has its raster share on the raster stream when this returns.
 int flush_raster(swr_context* c, uint64_t upto) {
+    if (c->ras_worker) {                                  // every posted share (and present) has been enqueued
+        const int rc = c->ras_worker->drain();
+        if (rc) return rc;
+    }
+    return enqueue_raster_shares(c, std::min(upto, c->posted));   // frames of the one-stream path (never posted)
+}
+
+// The raster stream's share of every frame below `upto` that has not been enqueued yet (caller's thread or ras_worker).
+int enqueue_raster_shares(swr_context* c, uint64_t upto) {
     for (;;) {
         const uint64_t g = c->ras_enqueued.load(std::memory_order_relaxed);
-        if (g >= upto || g >= c->posted) return SWR_OK;
-        while (c->bin_enqueued.load(std::memory_order_acquire) <= g) __builtin_ia32_pause();
+        if (g >= upto) return SWR_OK;
+        for (unsigned spins = 0; c->bin_enqueued.load(std::memory_order_acquire) <= g;)
+            if (++spins > 100000) std::this_thread::yield(); else __builtin_ia32_pause();
         if (c->bin_error.load(std::memory_order_relaxed)) {
             const int rc = c->bin_error.exchange(0);
-            c->ras_enqueued.store(c->posted, std::memory_order_release);
+            c->ras_enqueued.store(upto, std::memory_order_release);
             return rc ? rc : SWR_ERR_HIP;          // c->err was set by the helper
         }
-        swr_context::RasJob& rj = c->ras_job[g % swr_context::NSLOT];
+        swr_context::RasJob& rj = c->ras_job[g % swr_context::RAS_RING];
         swr_context::Slot& sl = c->slot[rj.si];
         hipStream_t sb = c->bin_stream, sr = c->stream;
-        c->hp_begin();
-        if (sb != sr) HIP_TRY(c, hipStreamWaitEvent(sr, sl.bin_done, 0));
-        c->hp_lap(3);
+        c->hp_begin_r();
+        if (sb != sr) {
+            if (c->ras_worker) { const int rc = poll_event(c, sl.bin_done); if (rc) return rc; }
+            else HIP_TRY(c, hipStreamWaitEvent(sr, sl.bin_done, 0));
+        }
+        c->hp_lap_r(3);
         { int rc = wait_for_copies_of(c, rj.fb, sr); if (rc) return rc; }
         if (rj.sort_here) launch_sort_bins(rj.f, sr);
         if (rj.ev3) HIP_TRY(c, hipEventRecord(rj.ev3, sr));
         launch_raster(rj.f, sr);
         if (rj.ev4) HIP_TRY(c, hipEventRecord(rj.ev4, sr));
-        c->hp_lap(4);
+        c->hp_lap_r(4);
         if (sb != sr) { HIP_TRY(c, hipEventRecord(sl.ras_done, sr)); sl.ras_recorded = true; }
-        c->hp_lap(5);
+        c->hp_lap_r(5);
         c->hp_frames++;
         HIP_TRY(c, hipGetLastError());
         c->ras_enqueued.store(g + 1, std::memory_order_release);
@@ -761,11 +813,19 @@ int single_draw(swr_context* c, const float transform[16], uint32_t flags, int32
 int enqueue_present(swr_context* c, void* color_full, float* depth_full) {
     const int fb = c->fb_last;
     if (tiles_of(c->tg) == 0) return SWR_OK;
-    int rc = flush_raster(c, c->frame_no);          // the frame being presented must be on the raster stream
-    if (rc) return rc;
-    HIP_TRY(c, hipEventRecord(c->frame_done[fb], c->stream));
-    if (color_full && !(c->last_flags & SWR_FLAG_NO_COLOR) && (rc = copy_band(c, fb, 0, color_full))) return rc;
-    if (depth_full && (rc = copy_band(c, fb, 1, depth_full))) return rc;
+    const bool want_color = color_full && !(c->last_flags & SWR_FLAG_NO_COLOR);
+    auto copies = [c, fb, want_color, color_full, depth_full]() -> int {
+        int rc;
+        HIP_TRY(c, hipEventRecord(c->frame_done[fb], c->stream));
+        if (want_color && (rc = copy_band(c, fb, 0, color_full))) return rc;
+        if (depth_full && (rc = copy_band(c, fb, 1, depth_full))) return rc;
+        return SWR_OK;
+    };
+    if (c->ras_worker) c->ras_worker->post(copies);   // behind the frame's raster share, in order
+    else {
+        int rc = flush_raster(c, c->frame_no);        // the frame being presented must be on the raster stream
+        if (rc || (rc = copies())) return rc;
+    }
     c->fb_cur = fb ^ 1;     // the next frame renders into the other framebuffer while this one is being copied
     if (c->frame_no) c->frame_presented[(c->frame_no - 1) % swr_context::PAIR_RING] = true;
     return SWR_OK;
@@ -864,6 +924,7 @@ int single_read(swr_context* c, int img, void* dst) {
 
 void destroy_single(swr_context* c) {
     hipSetDevice(c->device);
+    if (c->ras_worker) { c->ras_worker->drain(); c->ras_worker->stop(); delete c->ras_worker; c->ras_worker = nullptr; }
     if (c->bin_worker) { c->bin_worker->drain(); c->bin_worker->stop(); delete c->bin_worker; c->bin_worker = nullptr; }
     if (c->bin_stream) hipStreamSynchronize(c->bin_stream);
     if (c->stream) hipStreamSynchronize(c->stream);
@@ -931,6 +992,8 @@ int create_single(int dev, swr_context** out) {
             // SWR_HOST_THREADS=1: enqueue everything from the caller's thread (no helper)
             const char* ht = getenv("SWR_HOST_THREADS");
             if (c->bin_stream_own && !(ht && ht[0] == '1')) { c->bin_worker = new Worker(); c->bin_worker->start(dev); }
+            const char* ew = getenv("SWR_EVENT_WAITS");
+            if (c->bin_worker && !(ew && ew[0] == '1')) { c->ras_worker = new Worker(); c->ras_worker->start(dev); }
         }
         for (auto& sl : c->slot) {
             hipEventCreateWithFlags(&sl.bin_done, hipEventDisableTiming);

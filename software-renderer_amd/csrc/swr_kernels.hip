@@ -1476,9 +1476,25 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
         }
         const size_t at = (size_t)(y - a.tg.row_begin) * (size_t)W + (size_t)x;   // App.swift:351-360
         if (vec_ok && x + 3 <= X1) {
-            if (want_color)
-                *reinterpret_cast<uint4*>(a.color + at * 4) = make_uint4(cpix[0], cpix[1], cpix[2], cpix[3]);
-            *reinterpret_cast<float4*>(a.depth + at) = make_float4(dpix[0], dpix[1], dpix[2], dpix[3]);
+            // streaming stores: nothing on the GPU reads the framebuffer again, and 33 MB of dirty lines left in the
+            // L2s would be written back at the end of the kernel, in front of the next one
+            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+#ifndef SWR_NT_STORES
+#define SWR_NT_STORES 1
+#endif
+            if (SWR_NT_STORES) {
+                if (want_color) {
+                    u32x4 cv = {cpix[0], cpix[1], cpix[2], cpix[3]};
+                    __builtin_nontemporal_store(cv, reinterpret_cast<u32x4*>(a.color + at * 4));
+                }
+                f32x4 dv = {dpix[0], dpix[1], dpix[2], dpix[3]};
+                __builtin_nontemporal_store(dv, reinterpret_cast<f32x4*>(a.depth + at));
+            } else {
+                if (want_color)
+                    *reinterpret_cast<uint4*>(a.color + at * 4) = make_uint4(cpix[0], cpix[1], cpix[2], cpix[3]);
+                *reinterpret_cast<float4*>(a.depth + at) = make_float4(dpix[0], dpix[1], dpix[2], dpix[3]);
+            }
         } else {
             for (int k = 0; k < 4 && x + k <= X1; k++) {
                 if (want_color) reinterpret_cast<uint32_t*>(a.color)[at + k] = cpix[k];

@@ -776,6 +776,7 @@ struct RasterArgs {
     float* depth;       // band-local f32
     Target tg;
     int tag_class;      // bin entries carry a size class above bit CLASS_SHIFT
+    int vs_log;         // 2^vs_log workgroups per tile, each owning TILE_H >> vs_log of its rows (small grids, see launch_raster)
 };
 
 constexpr unsigned long long KEY_EMPTY = ~0ull;
@@ -934,7 +935,9 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
     constexpr bool EARLYZ = SWR_EARLYZ && ZTEST && !METAL;
     __shared__ uint32_t zmax_tab[RASTER_THREADS / 64][4];
 
-    const int tile = blockIdx.x;
+    const int tile = (int)(blockIdx.x >> a.vs_log);
+    const int part = (int)(blockIdx.x & ((1u << a.vs_log) - 1u));     // which slice of the tile's rows this workgroup owns
+    const int PROWS = TILE_H >> a.vs_log;
     const int tx = tile % a.tg.tiles_x, ty = tile / a.tg.tiles_x;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -942,6 +945,10 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
     const int X0 = tx * TILE_W, Y0 = a.tg.row_begin + ty * TILE_H;
     const int X1 = min(X0 + TILE_W, a.tg.width) - 1;
     const int Y1 = min(Y0 + TILE_H, a.tg.row_end) - 1;
+    // rows of the tile this workgroup walks and resolves (the whole tile unless the grid is split, vs_log > 0)
+    const int Yp0 = Y0 + part * PROWS;
+    const int Yp1 = min(Yp0 + PROWS - 1, Y1);
+    if (Yp0 > Y1) return;     // the band ends above this slice (workgroup-uniform)
 
     const bool overflow = a.counters[CNT_PAIRS] > a.capacity;
     const uint32_t b0 = overflow ? 0u : a.tile_start[tile];
@@ -968,9 +975,9 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
 #define SWR_ROWSPLIT_MAX 128
 #endif
     const bool rowsplit = m <= (uint32_t)SWR_ROWSPLIT_MAX;
-    constexpr int WROWS = TILE_H / (RASTER_THREADS / 64);
-    const int Yw0 = rowsplit ? Y0 + (tid >> 6) * WROWS : Y0;            // this wave's rows of the tile
-    const int Yw1 = rowsplit ? min(Yw0 + WROWS - 1, Y1) : Y1;
+    const int WROWS = PROWS / (RASTER_THREADS / 64);
+    const int Yw0 = rowsplit ? Yp0 + (tid >> 6) * WROWS : Yp0;          // this wave's rows of the tile
+    const int Yw1 = rowsplit ? min(Yw0 + WROWS - 1, Yp1) : Yp1;
     const bool spread = !rowsplit && gridDim.x <= 1536;   // fewer tiles than the chip holds workgroups (256 CUs x 6)
     const uint32_t csz = spread ? min(64u, max(1u, (m + RASTER_THREADS / 64 - 1) / (RASTER_THREADS / 64))) : 64u;
     const uint32_t nchunks = (m + csz - 1) / csz;
@@ -1375,7 +1382,7 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
     for (int i = tid; VAR != 8 && VAR != 10 && VAR != 11 && i < TILE_W * TILE_H / 4; i += RASTER_THREADS) {
         const int ly = (i * 4) / TILE_W, lx = (i * 4) % TILE_W;
         const int y = Y0 + ly, x = X0 + lx;
-        if (y > Y1 || x > X1) continue;
+        if (y < Yp0 || y > Yp1 || x > X1) continue;
         uint32_t cpix[4];
         float dpix[4];
         // neighbouring pixels usually share the winning primitive: its record, T() and vertex
@@ -1714,8 +1721,17 @@ void launch_raster(const DeviceFrame& f, hipStream_t s) {
     a.color = (f.flags & SWR_FLAG_NO_COLOR) ? nullptr : f.color;
     a.depth = f.depth; a.tg = f.tg;
     a.tag_class = f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0;
-    const unsigned tiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
-    if (tiles == 0) return;
+    const unsigned ntiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
+    if (ntiles == 0) return;
+    // Small grids (a small window: the reference app's 512x512 is 128 tiles): four workgroups fit where one tile's
+    // would run, so four share a tile, each walking and resolving its own 8 rows of it — the per-triangle setup is paid
+    // four times, the row steps and the pixel work are divided (the app's sphere: k_raster 19.9 -> 12.8 us, Metal rules
+    // 25.6 -> 14.3 us).  Two per tile for 320-640 tiles (1/8 band of cfg4: 510 dense tiles) measured no gain (23.3 vs
+    // 24.6 us): those workgroups are bound by the gather -> setup latency chain of their chunks, not by their rows
+    // (profiles/r02/vsplit_ab.txt).  SWR_VSPLIT=0/1/2 forces the log2 of the split.
+    static const int vs_mode = getenv("SWR_VSPLIT") ? atoi(getenv("SWR_VSPLIT")) : -1;
+    a.vs_log = vs_mode >= 0 ? std::min(vs_mode, 2) : (ntiles * 4 <= 1280 ? 2 : 0);
+    const unsigned tiles = ntiles << a.vs_log;
     const bool ext = f.material.shader != SWR_SHADER_PASSTHROUGH && a.color != nullptr;
     if (f.flags & SWR_FLAG_METAL_RULES) {
         if (ext) hipLaunchKernelGGL((k_raster<true, 0, true, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);

@@ -197,6 +197,9 @@ struct swr_context {
     // (and `bin_worker` does the same with ras_done before it re-uses a working set).  swr_draw / swr_present only post.
     // SWR_EVENT_WAITS=1: the caller's thread enqueues the raster share behind event waits (round-2 first half).
     Worker* ras_worker = nullptr;
+    // bin_done / ras_done are bound to the kernels they follow (hipExtLaunchKernelGGL's stop event) instead of being
+    // recorded behind them: a marker packet between two kernels of a queue costs the second one ~6.5 us.  SWR_BIND_EVENTS=0: record.
+    bool bind_events = true;
     std::atomic<uint64_t> bin_enqueued{0};      // frames whose binning (incl. the bin_done record) is on the binning stream
     std::atomic<uint64_t> ras_enqueued{0};      // frames whose raster (incl. the ras_done record) is on the raster stream
     std::atomic<int> bin_error{0};
@@ -485,9 +488,11 @@ int enqueue_frame(swr_context* c) {
         if (e1) HIP_TRY(c, hipEventRecord(e1, sb));
         launch_scan(f, sb);
         if (e2) HIP_TRY(c, hipEventRecord(e2, sb));
-        launch_fill(f, sb);
-        if (!sort_on_raster_stream) launch_sort_bins(f, sb);
-        if (sb != sr) HIP_TRY(c, hipEventRecord(sl.bin_done, sb));
+        // bin_done = the completion of the chain's last kernel itself (bound at launch) where there is one
+        hipEvent_t stop = (sb != sr && c->bind_events) ? sl.bin_done : nullptr;
+        bool bound = launch_fill(f, sb, sort_on_raster_stream ? stop : nullptr);
+        if (!sort_on_raster_stream) bound = launch_sort_bins(f, sb, stop);
+        if (sb != sr && !bound) HIP_TRY(c, hipEventRecord(sl.bin_done, sb));
         HIP_TRY(c, hipGetLastError());
         return SWR_OK;
     };
@@ -551,10 +556,10 @@ int enqueue_raster_shares(swr_context* c, uint64_t upto) {
         { int rc = wait_for_copies_of(c, rj.fb, sr); if (rc) return rc; }
         if (rj.sort_here) launch_sort_bins(rj.f, sr);
         if (rj.ev3) HIP_TRY(c, hipEventRecord(rj.ev3, sr));
-        launch_raster(rj.f, sr);
+        const bool bound = launch_raster(rj.f, sr, (sb != sr && c->bind_events) ? sl.ras_done : nullptr);
         if (rj.ev4) HIP_TRY(c, hipEventRecord(rj.ev4, sr));
         c->hp_lap_r(4);
-        if (sb != sr) { HIP_TRY(c, hipEventRecord(sl.ras_done, sr)); sl.ras_recorded = true; }
+        if (sb != sr) { if (!bound) HIP_TRY(c, hipEventRecord(sl.ras_done, sr)); sl.ras_recorded = true; }
         c->hp_lap_r(5);
         c->hp_frames++;
         HIP_TRY(c, hipGetLastError());
@@ -992,6 +997,7 @@ int create_single(int dev, swr_context** out) {
             // SWR_HOST_THREADS=1: enqueue everything from the caller's thread (no helper)
             const char* ht = getenv("SWR_HOST_THREADS");
             if (c->bin_stream_own && !(ht && ht[0] == '1')) { c->bin_worker = new Worker(); c->bin_worker->start(dev); }
+            { const char* be = getenv("SWR_BIND_EVENTS"); c->bind_events = !(be && be[0] == '0'); }
             const char* ew = getenv("SWR_EVENT_WAITS");
             if (c->bin_worker && !(ew && ew[0] == '1')) { c->ras_worker = new Worker(); c->ras_worker->start(dev); }
         }

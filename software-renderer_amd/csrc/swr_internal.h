@@ -121,9 +121,10 @@ void launch_gather_attrs(const swr_vertex_attr* attrs, int64_t nv, const int64_t
 void launch_texture_to_float(const uint32_t* bgra, int64_t n, float4* out, hipStream_t s);
 void launch_setup_bin(const DeviceFrame& f, hipStream_t s);
 void launch_scan(const DeviceFrame& f, hipStream_t s);
-void launch_fill(const DeviceFrame& f, hipStream_t s);
-void launch_sort_bins(const DeviceFrame& f, hipStream_t s);
-void launch_raster(const DeviceFrame& f, hipStream_t s);
+// stop != NULL: the event is bound to the (last) kernel launched, as its completion; returns whether a kernel carries it
+bool launch_fill(const DeviceFrame& f, hipStream_t s, hipEvent_t stop = nullptr);
+bool launch_sort_bins(const DeviceFrame& f, hipStream_t s, hipEvent_t stop = nullptr);
+bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop = nullptr);
 void launch_points_or_lines(const DeviceFrame& f, int primitive_type, hipStream_t s);
 
 }  // namespace swr

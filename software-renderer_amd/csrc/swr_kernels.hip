@@ -41,6 +41,7 @@
 // Float discipline: compiled with -ffp-contract=off; only + - * / in the order of the
 // reference; IEEE-correct division; the same expressions in setup, raster and resolve.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
 
@@ -1651,6 +1652,14 @@ hipError_t prepare_device() {
     return hipFuncSetAttribute((const void*)k_fill_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
+// Launch with the completion of the kernel bound to `stop` (hipExtLaunchKernelGGL: the event is the kernel's own
+// completion signal — no marker packet behind the kernel, which would cost the next kernel of the queue ~6.5 us).
+#define SWR_LAUNCH(stop, kernel, grid, block, lds, stream, ...)                                         \
+    do {                                                                                              \
+        if (stop) hipExtLaunchKernelGGL(kernel, grid, block, lds, stream, nullptr, stop, 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                        \
+    } while (0)
+
 void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
     if (f.ntri <= 0) return;
     const SetupArgs a = make_setup_args(f);
@@ -1678,35 +1687,38 @@ void launch_scan(const DeviceFrame& f, hipStream_t s) {
                        f.counters, f.host_counters, f.capacity);
 }
 
-void launch_fill(const DeviceFrame& f, hipStream_t s) {
-    if (f.ntri <= 0) return;
+bool launch_fill(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
+    if (f.ntri <= 0) return false;
     const int ntiles = f.tg.tiles_x * f.tg.tiles_y;
     if (f.plan.use_lds) {
+        const int per = live_groups_per_workgroup(f.ntri, f.plan.G);
+        const int tagged = f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0;
         if (f.plan.threads == 256)
-            hipLaunchKernelGGL(k_fill_lds<256>, dim3(f.plan.G), dim3(256), f.plan.lds_bytes + 4 * 256, s, f.ranges, f.ntri,
-                               f.bin_matrix, f.tile_count, f.tile_start, f.counters, f.host_counters, f.bins,
-                               f.capacity, f.live, live_groups_per_workgroup(f.ntri, f.plan.G), ntiles,
-                               f.tg.tiles_x, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
+            SWR_LAUNCH(stop, k_fill_lds<256>, dim3(f.plan.G), dim3(256), (uint32_t)(f.plan.lds_bytes + 4 * 256), s,
+                       (const uint2*)f.ranges, f.ntri, (const uint32_t*)f.bin_matrix, (const uint32_t*)f.tile_count, f.tile_start,
+                       f.counters, f.host_counters, f.bins, f.capacity, (const uint32_t*)f.live, per, ntiles, (int)f.tg.tiles_x, tagged);
         else
-            hipLaunchKernelGGL(k_fill_lds<BIN_THREADS>, dim3(f.plan.G), dim3(BIN_THREADS), f.plan.lds_bytes + 4 * BIN_THREADS, s,
-                               f.ranges, f.ntri, f.bin_matrix, f.tile_count, f.tile_start, f.counters, f.host_counters,
-                               f.bins, f.capacity, f.live, live_groups_per_workgroup(f.ntri, f.plan.G), ntiles,
-                               f.tg.tiles_x, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
+            SWR_LAUNCH(stop, k_fill_lds<BIN_THREADS>, dim3(f.plan.G), dim3(BIN_THREADS), (uint32_t)(f.plan.lds_bytes + 4 * BIN_THREADS), s,
+                       (const uint2*)f.ranges, f.ntri, (const uint32_t*)f.bin_matrix, (const uint32_t*)f.tile_count, f.tile_start,
+                       f.counters, f.host_counters, f.bins, f.capacity, (const uint32_t*)f.live, per, ntiles, (int)f.tg.tiles_x, tagged);
     } else {
         const unsigned blocks = (unsigned)((f.ntri + 255) / 256);
         hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, s, f.ranges, f.ntri, f.tile_cursor, f.counters,
                            f.bins, f.capacity, f.tg.tiles_x, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
+        return false;
     }
+    return stop != nullptr;
 }
 
-void launch_sort_bins(const DeviceFrame& f, hipStream_t s) {
+bool launch_sort_bins(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     const unsigned tiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
-    if (f.ntri <= 0 || tiles == 0) return;
-    hipLaunchKernelGGL(k_sort_bins, dim3(tiles), dim3(SORT_THREADS), 0, s, f.bins, f.tile_start, f.counters,
-                       f.capacity, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
+    if (f.ntri <= 0 || tiles == 0) return false;
+    SWR_LAUNCH(stop, k_sort_bins, dim3(tiles), dim3(SORT_THREADS), 0, s, f.bins, (const uint32_t*)f.tile_start,
+               (const uint32_t*)f.counters, f.capacity, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
+    return stop != nullptr;
 }
 
-void launch_raster(const DeviceFrame& f, hipStream_t s) {
+bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     RasterArgs a;
     a.geo = f.geo; a.geo_full = f.geo_full; a.tri_rgb = f.tri_rgb;
     a.inv = f.inv; a.reordered = f.reordered;
@@ -1722,7 +1734,7 @@ void launch_raster(const DeviceFrame& f, hipStream_t s) {
     a.depth = f.depth; a.tg = f.tg;
     a.tag_class = f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0;
     const unsigned ntiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
-    if (ntiles == 0) return;
+    if (ntiles == 0) return false;
     // Small grids (a small window: the reference app's 512x512 is 128 tiles): four workgroups fit where one tile's
     // would run, so four share a tile, each walking and resolving its own 8 rows of it — the per-triangle setup is paid
     // four times, the row steps and the pixel work are divided (the app's sphere: k_raster 19.9 -> 12.8 us, Metal rules
@@ -1734,16 +1746,16 @@ void launch_raster(const DeviceFrame& f, hipStream_t s) {
     const unsigned tiles = ntiles << a.vs_log;
     const bool ext = f.material.shader != SWR_SHADER_PASSTHROUGH && a.color != nullptr;
     if (f.flags & SWR_FLAG_METAL_RULES) {
-        if (ext) hipLaunchKernelGGL((k_raster<true, 0, true, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-        else hipLaunchKernelGGL((k_raster<true, 0, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-        return;
+        if (ext) SWR_LAUNCH(stop, (k_raster<true, 0, true, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        else SWR_LAUNCH(stop, (k_raster<true, 0, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        return stop != nullptr;
     }
     if (ext) {
         if (f.flags & SWR_FLAG_DEPTH_TEST)
-            hipLaunchKernelGGL((k_raster<true, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+            SWR_LAUNCH(stop, (k_raster<true, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else
-            hipLaunchKernelGGL((k_raster<false, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-        return;
+            SWR_LAUNCH(stop, (k_raster<false, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        return stop != nullptr;
     }
 #ifdef SWR_ABLATION
     // timing-only ablations of k_raster<ztest> (results invalid): compiled only into lib/libswr_hip_ablation.so
@@ -1751,7 +1763,7 @@ void launch_raster(const DeviceFrame& f, hipStream_t s) {
     static const int variant = getenv("SWR_DEBUG_VARIANT") ? atoi(getenv("SWR_DEBUG_VARIANT")) : 0;
     if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant > 0) {
         switch (variant) {
-#define SWR_V(N) case N: hipLaunchKernelGGL((k_raster<true, N>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a); return;
+#define SWR_V(N) case N: hipLaunchKernelGGL((k_raster<true, N>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a); return false;
             SWR_V(1) SWR_V(2) SWR_V(3) SWR_V(4) SWR_V(5) SWR_V(8) SWR_V(9) SWR_V(10) SWR_V(11)
 #undef SWR_V
             default: break;
@@ -1759,9 +1771,10 @@ void launch_raster(const DeviceFrame& f, hipStream_t s) {
     }
 #endif
     if (f.flags & SWR_FLAG_DEPTH_TEST)
-        hipLaunchKernelGGL(k_raster<true>, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        SWR_LAUNCH(stop, k_raster<true>, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
     else
-        hipLaunchKernelGGL(k_raster<false>, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        SWR_LAUNCH(stop, k_raster<false>, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+    return stop != nullptr;
 }
 
 }  // namespace swr

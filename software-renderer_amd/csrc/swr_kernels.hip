@@ -430,6 +430,8 @@ __device__ __forceinline__ void for_each_tile(const PixBox& b, uint32_t p, F&& f
     }
 }
 
+__device__ __forceinline__ int wave_incl_add(int v);
+
 // Workgroup size of the two binning walks (template parameter BT of k_setup_hist / k_fill_lds): 256 threads.
 // A 256-thread workgroup (44-52 VGPRs, one wave per SIMD, <= 16 KB of LDS) fits on a CU beside five resident
 // raster workgroups, so the binning of frame N+1 really runs WHILE frame N is rasterised; a 1024-thread one
@@ -534,6 +536,10 @@ __global__ __launch_bounds__(BT) void k_setup_hist(SetupArgs a, uint32_t* __rest
             r = setup_triangle(a, p);
             a.ranges[p] = r;
         }
+        // (one atomic per run of neighbouring lanes with the same tile instead of one per lane — the stream is
+        // Morton-ordered, so these are 16- to 64-way same-address conflicts — was measured SLOWER: k_setup_hist 28.9 ->
+        // 34.5 us, k_fill_lds 25.7 -> 33.8 us, profiles/r02/bin_aggregate_ab.txt: the LDS resolves same-address atomics
+        // faster than the wave can find its runs)
         for_each_tile(unpack_box(r), (uint32_t)p, [&](const PixBox&, uint32_t, int tx, int ty) {
             atomicAdd(&hist[ty * tiles_x + tx], 1u);
         });
@@ -603,16 +609,21 @@ __global__ __launch_bounds__(BT) void k_fill_lds(const uint2* __restrict__ range
     const int sb = t * per, se = min(sb + per, ntiles);
     uint32_t sum = 0;
     for (int i = sb; i < se; i++) sum += cursor[i];
-    part[t] = sum;
+    // exclusive prefix of the per-thread sums: a DPP scan inside every wave, then wave 0 scans the wave totals
+    // (two barriers; the Hillis-Steele ladder over LDS this replaces took 2 log2(BT) = 20)
+    static_assert(BT % 64 == 0 && BT / 64 <= 64, "one wave scans the wave totals");
+    const uint32_t incl = (uint32_t)wave_incl_add((int)sum);
+    if ((t & 63) == 63) part[t >> 6] = incl;
     __syncthreads();
-    for (int off = 1; off < BT; off <<= 1) {
-        const uint32_t v = (t >= off) ? part[t - off] : 0u;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
+    if (t < 64) {
+        const uint32_t v = t < BT / 64 ? part[t] : 0u;
+        const uint32_t wi = (uint32_t)wave_incl_add((int)v);
+        if (t < BT / 64) part[t] = wi - v;
+        if (t == BT / 64 - 1) part[BT / 64] = wi;
     }
-    const uint32_t total = part[BT - 1];
-    uint32_t run = part[t] - sum;
+    __syncthreads();
+    const uint32_t total = part[BT / 64];
+    uint32_t run = part[t >> 6] + incl - sum;
     for (int i = sb; i < se; i++) { const uint32_t c = cursor[i]; cursor[i] = run; run += c; }
     __syncthreads();
     if (blockIdx.x == 0) {

@@ -160,7 +160,19 @@ struct swr_context {
 #ifndef SWR_NSLOT
 #define SWR_NSLOT 3   // working sets in flight: binning may run up to two frames ahead of the raster (2 -> 3: -3 %)
 #endif
+#ifndef SWR_RAS_EVERY
+#define SWR_RAS_EVERY 1   // every n-th k_raster carries a completion event (see RAS_EVERY)
+#endif
     static constexpr int NSLOT = SWR_NSLOT;
+    // A kernel that carries a completion signal (ras_done) costs the NEXT kernel of its queue ~5 us
+    // (profiles/r02/c_kernel_trace_pipelined.txt).  The binning of frame N needs "k_raster(N - NSLOT) has finished"; it
+    // waits for the first event-carrying raster at or after that frame instead (same queue, in order), so only every
+    // RAS_EVERY-th raster needs one, at the price of RAS_EVERY - 1 extra working sets.  Measured (NSLOT / RAS_EVERY = 3 / 1,
+    // 4 / 2, 6 / 4; profiles/r02/ras_every_ab.txt): cfg4 0.0977 / 0.0993 / 0.0981 ms, 1/8 band 29.2 / 27.7 / 27.0 us — the
+    // gap on the raster queue is filled by the binning queue's kernels (the frame is bound by the sum of the work), so
+    // the default stays 3 / 1.
+    static constexpr int RAS_EVERY = SWR_RAS_EVERY;
+    static_assert(RAS_EVERY >= 1 && NSLOT > RAS_EVERY, "the event-carrying raster must be older than the frame being binned");
     // Per-frame working set, multi-buffered: the binning kernels of frame N+1 run on `bin_stream`
     // while k_raster of frame N runs on `stream` (HBM-bound vs LDS/VALU-bound: they overlap well).
     struct Slot {
@@ -168,11 +180,12 @@ struct swr_context {
         DevBuf live;           // per binning workgroup: count + surviving stream-group ids (k_setup_hist -> k_fill_lds)
         DevBuf tilebuf;        // [CNT_WORDS counters][tiles tile_count][tiles+1 tile_start][tiles cursor]
         hipEvent_t bin_done = nullptr, ras_done = nullptr;
-        bool ras_recorded = false;
+        uint64_t ras_event_frame = ~0ull;   // the frame whose k_raster this slot's ras_done tracks (none yet)
     } slot[NSLOT];
     hipStream_t bin_stream = nullptr;   // the stream binning is enqueued on (== stream when pipelining is off)
     hipStream_t bin_stream_own = nullptr;
     uint64_t frame_no = 0;
+    uint64_t synced_upto = 0;           // every frame below this has completed (full stream sync seen by the caller)
     int last_slot = 0;
     uint32_t capacity = 0;
 
@@ -312,6 +325,7 @@ int sync_streams(swr_context* c) {
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->bin_stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
+    c->synced_upto = c->frame_no;
     return SWR_OK;
 }
 
@@ -468,16 +482,22 @@ int enqueue_frame(swr_context* c) {
     const size_t zero_bytes = (size_t)(CNT_WORDS + 3 * tiles_of(c->tg) + 1) * 4;
     hipEvent_t e0 = (ev && all) ? ev[0] : nullptr, e1 = (ev && all) ? ev[1] : nullptr, e2 = (ev && all) ? ev[2] : nullptr;
     // ---- the binning stream's share of the frame ----
-    auto bin_share = [c, f, si, sb, sr, frame, zero_tables, zero_bytes, e0, e1, e2, sort_on_raster_stream]() -> int {
+    // this slot's buffers are free again once the raster of NSLOT frames ago has read them (a full sync since then
+    // settles it: every non-pipelined path syncs first)
+    const bool slot_wait = sb != sr && frame >= (uint64_t)swr_context::NSLOT && frame - (uint64_t)swr_context::NSLOT >= c->synced_upto;
+    auto bin_share = [c, f, si, sb, sr, frame, zero_tables, zero_bytes, e0, e1, e2, sort_on_raster_stream, slot_wait]() -> int {
         swr_context::Slot& sl = c->slot[si];
-        if (sb != sr && frame >= (uint64_t)swr_context::NSLOT) {
-            // this slot's buffers are free again once the raster of NSLOT frames ago has read them: its ras_done must
-            // have been RECORDED (by the caller's thread) before the wait on it is enqueued
-            for (unsigned spins = 0; c->ras_enqueued.load(std::memory_order_acquire) + (uint64_t)swr_context::NSLOT <= frame;)
+        if (slot_wait) {
+            // the first event-carrying raster at or after that frame (RAS_EVERY); its event must have been bound /
+            // recorded (by ras_worker or the caller's thread) before it is polled / waited for
+            const uint64_t prev = frame - (uint64_t)swr_context::NSLOT;
+            const uint64_t ef = prev + (uint64_t)(swr_context::RAS_EVERY - 1) - prev % (uint64_t)swr_context::RAS_EVERY;
+            for (unsigned spins = 0; c->ras_enqueued.load(std::memory_order_acquire) <= ef;)
                 if (++spins > 100000) std::this_thread::yield(); else __builtin_ia32_pause();
-            if (sl.ras_recorded) {
-                if (c->ras_worker) { const int rc = poll_event(c, sl.ras_done); if (rc) return rc; }
-                else HIP_TRY(c, hipStreamWaitEvent(sb, sl.ras_done, 0));
+            swr_context::Slot& es = c->slot[ef % (uint64_t)swr_context::NSLOT];
+            if (es.ras_event_frame == ef) {
+                if (c->ras_worker) { const int rc = poll_event(c, es.ras_done); if (rc) return rc; }
+                else HIP_TRY(c, hipStreamWaitEvent(sb, es.ras_done, 0));
             }
         }
         // global-atomic fallback: counters must start at zero.  Empty scene: no binning kernel runs at all, so the
@@ -556,10 +576,11 @@ int enqueue_raster_shares(swr_context* c, uint64_t upto) {
         { int rc = wait_for_copies_of(c, rj.fb, sr); if (rc) return rc; }
         if (rj.sort_here) launch_sort_bins(rj.f, sr);
         if (rj.ev3) HIP_TRY(c, hipEventRecord(rj.ev3, sr));
-        const bool bound = launch_raster(rj.f, sr, (sb != sr && c->bind_events) ? sl.ras_done : nullptr);
+        const bool carries = sb != sr && g % (uint64_t)swr_context::RAS_EVERY == (uint64_t)(swr_context::RAS_EVERY - 1);
+        const bool bound = launch_raster(rj.f, sr, (carries && c->bind_events) ? sl.ras_done : nullptr);
         if (rj.ev4) HIP_TRY(c, hipEventRecord(rj.ev4, sr));
         c->hp_lap_r(4);
-        if (sb != sr) { if (!bound) HIP_TRY(c, hipEventRecord(sl.ras_done, sr)); sl.ras_recorded = true; }
+        if (carries) { if (!bound) HIP_TRY(c, hipEventRecord(sl.ras_done, sr)); sl.ras_event_frame = g; }
         c->hp_lap_r(5);
         c->hp_frames++;
         HIP_TRY(c, hipGetLastError());

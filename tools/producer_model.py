@@ -89,3 +89,69 @@ for nm, sel in (("dense tiles (chunk per wave)", cdense), ("row-split tiles (x4 
 print(f"  empty-span row steps: {(px == 0).sum()} of {len(px)} ({(px == 0).mean():.3f})")
 hist = np.bincount(np.minimum(pair_rows, 33))
 print("  rows per pair histogram:", hist.tolist())
+# how many wave steps run with few active lanes (the tail of a chunk: its longest triangles)
+srt_steps = ps  # per pair, ordered by (tile, -rows)
+import collections
+tail = collections.Counter()
+cstart = np.flatnonzero(np.r_[1, np.diff(chunk_id)])
+cend = np.r_[cstart[1:], len(ps)]
+tot_steps = 0
+lane_steps_tail = collections.Counter()
+for T in (4, 8, 16, 24, 32):
+    ws = 0; ls = 0
+    for a0, b0 in zip(cstart[:20000], cend[:20000]):
+        st = np.sort(ps[a0:b0])[::-1]
+        smax = st[0]
+        sT = st[T - 1] if len(st) >= T else 0
+        ws += smax - sT                      # steps during which fewer than T lanes are active
+        ls += np.maximum(st[:T - 1] - sT, 0).sum()   # lane-steps done in them
+    print(f"  first 20000 chunks: steps with < {T} active lanes: {ws} of {csteps[:20000].sum()}  ({ws / csteps[:20000].sum():.3f}), lane-steps in them {ls}")
+t0 = pt[len(pt) // 2]
+sel = pt == t0
+print("  one tile:", t0, "pairs", sel.sum())
+rr, ss = pr[sel], ps[sel]
+for c0 in range(0, len(rr), 64):
+    print("   chunk rows", rr[c0:c0 + 64].tolist()[:64:4], " steps max", ss[c0:c0 + 64].max(), "sum", ss[c0:c0 + 64].sum(), "sorted steps top", np.sort(ss[c0:c0+64])[::-1][:10].tolist())
+# --- alternative sort keys for the bins: estimated row steps instead of rows ---
+pair_lo = np.full(len(uk), 1 << 30); pair_hi = np.full(len(uk), -1)
+np.minimum.at(pair_lo, inv, np.where(px > 0, l2, 1 << 30)); np.maximum.at(pair_hi, inv, np.where(px > 0, h2, -1))
+# clipped bbox columns as the kernel sees them (bbox of the triangle ∩ tile), not of the spans
+bx0p = np.maximum(bx0[rep], col * TW); bx1p = np.minimum(bx1[rep], col * TW + TW - 1)
+pair_cols = np.zeros(len(uk), np.int64); np.maximum.at(pair_cols, inv, bx1p - bx0p + 1)
+def total_steps(key, label):
+    order = np.lexsort((-key, pair_tile))
+    pt2, ps2 = pair_tile[order], pair_steps[order]
+    first = np.r_[0, np.flatnonzero(np.diff(pt2)) + 1]
+    cnt = np.diff(np.r_[first, len(pt2)])
+    pos = np.arange(len(pt2)) - np.repeat(first, cnt)
+    cid = np.cumsum(np.r_[1, (np.diff(pt2) != 0) | (pos[1:] % 64 == 0)]) - 1
+    cs = np.zeros(cid[-1] + 1, np.int64); np.maximum.at(cs, cid, ps2)
+    print(f"  sort by {label}: wave steps {cs.sum()}  utilisation {pair_steps.sum() / (64 * cs.sum()):.3f}")
+total_steps(pair_rows, "rows (today)")
+total_steps(pair_steps, "exact steps (bound)")
+total_steps(pair_rows * np.maximum(1, (pair_cols + 12) // 24), "rows * max(1,(cols+12)/24)")
+total_steps(pair_rows + pair_rows * np.maximum(0, pair_cols - 12) // np.maximum(pair_cols, 1), "rows + rows*(cols-12)/cols")
+total_steps(pair_rows + pair_rows * np.maximum(0, pair_cols - 12) // (2 * np.maximum(pair_cols, 1)), "rows + rows*(cols-12)/(2 cols)")
+total_steps(pair_rows * 64 + pair_cols, "rows, then cols")
+total_steps(pair_rows + (pair_cols > 12) * pair_rows // 3, "rows + (cols>12) rows/3")
+def est(rows, cols, a, lim=12):
+    e = rows.copy()
+    for k in range(1, 6):
+        e = e + rows * np.maximum(0, cols - a - lim * (k - 1)) // np.maximum(cols, 1)
+    return e
+for a in (8, 10, 12, 14):
+    total_steps(est(pair_rows, pair_cols, a), f"rows + sum_k rows*(cols-{a}-12(k-1))/cols")
+total_steps(2 * pair_rows + 2 * pair_rows * np.maximum(0, pair_cols - 12) // np.maximum(pair_cols, 1), "2x resolution of rows + rows*(cols-12)/cols")
+# per-triangle widest span = 2*Area / height (exact for a triangle), clipped by the pair's bbox columns
+ax, ay = tx[:, 0], ty[:, 0]; bx, by = tx[:, 1], ty[:, 1]; cxx, cyy = tx[:, 2], ty[:, 2]
+area2 = np.abs((bx - ax) * (cyy - ay) - (cxx - ax) * (by - ay))
+hh = np.maximum(ty[:, 2] - ty[:, 0], 1)
+maxspan = area2 // hh + 1
+pair_tri = uk % n
+ms = np.minimum(maxspan[pair_tri], pair_cols)
+for a in (10, 12):
+    total_steps(est(pair_rows, ms, a), f"rows + sum_k rows*(ms-{a}-12(k-1))/ms, ms = min(2A/h+1, cols)")
+    total_steps(est(2 * pair_rows, ms, a), f"2x: rows + sum_k rows*(ms-{a}-12(k-1))/ms")
+tt = sum(np.maximum(0, pair_cols - 10 - 12 * k) for k in range(5))
+e1 = pair_rows + (pair_rows * tt / np.maximum(pair_cols, 1)).astype(np.int64)
+total_steps(np.minimum(e1 - 1, 62), "KERNEL FORMULA: min(rows + rows*T(cols)/cols - 1, 62)")

@@ -261,3 +261,41 @@ def test_group_resident_path_and_timings(swr, oracle):
     same(c, d, rc_c, rc_d, "group resident")
     assert np.array_equal(c2[256:640], rc_c[256:640]) and d2[256:640].tobytes() == rc_d[256:640].tobytes()
     assert (d2[:256] == 3.0).all() and (d2[640:] == 3.0).all() and not c2[:256].any()
+
+
+@pytest.mark.parametrize("env", [{}, {"SWR_EVENT_WAITS": "1"}, {"SWR_HOST_THREADS": "1"}, {"SWR_BIND_EVENTS": "0"},
+                                 {"SWR_PIPELINE": "0"}, {"SWR_EVENT_WAITS": "1", "SWR_BIND_EVENTS": "0"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")
+@pytest.mark.parametrize("n", [1, 3])
+def test_every_frame_of_an_unwaited_burst_is_intact_under_every_ordering_mode(swr, oracle, monkeypatch, env, n):
+    """Eight frames with eight different transforms, drawn and presented into eight host image sets without a single
+    wait in between: three working sets and two device framebuffers are re-used while earlier frames are still in
+    flight.  The streams are ordered by the helper threads' event polls (default), by event waits on the streams
+    (SWR_EVENT_WAITS=1 / SWR_HOST_THREADS=1), with recorded instead of kernel-bound events, or not at all (one stream);
+    the pixels must not depend on which (include/swr.h: the knobs of INTEGRATION.md §7 only change timing)."""
+    S = swr.scenes
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    s = S.random_soup(30000, 640, 352, 0xB0B5, r_ndc=0.05, flags=DT, margin=1.1)
+    W, H = s.width, s.height
+    mats = []
+    for k in range(8):                            # column-major: scale about the centre + a shift, w = 1
+        m = np.eye(4, dtype=np.float32)
+        m[0, 0] = 0.75 + 0.05 * k; m[1, 1] = 1.1 - 0.04 * k
+        m[3, 0] = 0.03 * k - 0.1; m[3, 1] = 0.05 - 0.02 * k
+        mats.append(np.ascontiguousarray(m).reshape(16))
+    imgs = [(swr.HostImage((H, W, 4), np.uint8), swr.HostImage((H, W), np.float32)) for _ in mats]
+    with swr.Context(0, device_count=n) as ctx:
+        ctx.scene_upload(s.vertices, s.indices)
+        ctx.target_set(W, H)
+        for rep in range(3):                      # three bursts: the second and third start with everything warm
+            for m, (ci, di) in zip(mats, imgs):
+                ctx.draw(m, DT)
+                ctx.present(ci, di)
+            ctx.present_wait()
+    for k, m in enumerate(mats):
+        rc_c, rc_d, _, code = oracle.render(s.vertices, s.indices, m, W, H, DT)
+        assert code == 0
+        same(imgs[k][0].array, imgs[k][1].array, rc_c, rc_d, f"burst frame {k} ({env or 'default'}, n={n})")
+    for a, b in imgs:
+        a.free(); b.free()

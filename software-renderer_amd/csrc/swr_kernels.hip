@@ -270,11 +270,14 @@ __device__ __forceinline__ void decode_vertices(const GeomFull* __restrict__ ful
 // truncation, y-sort, T(); writes the 32-B GeomRec and returns the triangle's bbox
 // clipped to the band, in pixels: x = x0 | x1 << 16, y = (y0 - row_begin) | (y1 - row_begin) << 16
 // (RANGE_NONE_X when the bbox misses the band).
+__device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p, const float4& xa, const float4& xb, const float4& xc);
 __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
-    uint2 range = make_uint2(RANGE_NONE_X, 0u);
-
     // :223-227 — the three vertex references of the primitive in slot p, in index order (de-indexed at upload)
-    const float4 xa = a.tri_xyz[3 * p + 0], xb = a.tri_xyz[3 * p + 1], xc = a.tri_xyz[3 * p + 2];
+    return setup_triangle(a, p, a.tri_xyz[3 * p + 0], a.tri_xyz[3 * p + 1], a.tri_xyz[3 * p + 2]);
+}
+// ... with the corners already loaded (k_setup_hist fetches those of its next group while it works on this one)
+__device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p, const float4& xa, const float4& xb, const float4& xc) {
+    uint2 range = make_uint2(RANGE_NONE_X, 0u);
     const uint32_t orig = a.reordered ? __float_as_uint(xa.w) : 0u;
     // vertex colours are passed through by vertex_shader untouched (Shaders.metal:53) and are only
     // consumed by the resolve, which fetches them for the winning primitive through idx32 / rgb
@@ -529,11 +532,25 @@ __global__ __launch_bounds__(BT) void k_setup_hist(SetupArgs a, uint32_t* __rest
         for (uint32_t i = threadIdx.x; i < nlive; i += BT) out[1 + i] = mylist[i];
     }
     const int tiles_x = a.tg.tiles_x;
-    for (uint32_t j = threadIdx.x >> 6; j < nlive; j += BT / 64) {   // per wave
+    // per wave; the 48 B per lane of the NEXT group are in flight while this one is transformed (the loop is a chain of
+    // HBM round trips otherwise: four groups per wave, one wave per SIMD)
+    float4 nxa = make_float4(0, 0, 0, 0), nxb = nxa, nxc = nxa;
+    {
+        const uint32_t j0 = threadIdx.x >> 6;
+        const int64_t p0 = j0 < nlive ? ((int64_t)mylist[j0] << 6) + (threadIdx.x & 63) : a.ntri;
+        if (p0 < a.ntri) { nxa = a.tri_xyz[3 * p0 + 0]; nxb = a.tri_xyz[3 * p0 + 1]; nxc = a.tri_xyz[3 * p0 + 2]; }
+    }
+    for (uint32_t j = threadIdx.x >> 6; j < nlive; j += BT / 64) {
         const int64_t p = ((int64_t)mylist[j] << 6) + (threadIdx.x & 63);
+        const float4 xa = nxa, xb = nxb, xc = nxc;
+        {
+            const uint32_t jn = j + BT / 64;
+            const int64_t pn = jn < nlive ? ((int64_t)mylist[jn] << 6) + (threadIdx.x & 63) : a.ntri;
+            if (pn < a.ntri) { nxa = a.tri_xyz[3 * pn + 0]; nxb = a.tri_xyz[3 * pn + 1]; nxc = a.tri_xyz[3 * pn + 2]; }
+        }
         uint2 r = make_uint2(RANGE_NONE_X, 0u);
         if (p < a.ntri) {
-            r = setup_triangle(a, p);
+            r = setup_triangle(a, p, xa, xb, xc);
             a.ranges[p] = r;
         }
         // (one atomic per run of neighbouring lanes with the same tile instead of one per lane — the stream is
@@ -641,13 +658,26 @@ __global__ __launch_bounds__(BT) void k_fill_lds(const uint2* __restrict__ range
     __syncthreads();
     const uint32_t* mylist = live + (size_t)blockIdx.x * (size_t)(gper + 1);   // published by k_setup_hist
     const uint32_t nlive = mylist[0];
-    for (uint32_t j = t >> 6; j < nlive; j += BT / 64) {   // same groups, same order as k_setup_hist
-        const int64_t p = ((int64_t)mylist[1 + j] << 6) + (t & 63);
-        const uint2 r = p < ntri ? ranges[p] : make_uint2(RANGE_NONE_X, 0u);
-        for_each_tile(unpack_box(r), (uint32_t)p, [&](const PixBox& b, uint32_t prim, int tx, int ty) {
-            const uint32_t pos = atomicAdd(&cursor[ty * tiles_x + tx], 1u);
-            bins[pos] = prim | (tag_class ? size_class(b, tx, ty) << CLASS_SHIFT : 0u);
-        });
+    // same groups, same order as k_setup_hist; the boxes of four groups are fetched together (the walk is otherwise one
+    // HBM round trip per group, four or more per wave)
+    constexpr int FB = 4;
+    for (uint32_t j0 = t >> 6; j0 < nlive; j0 += FB * (BT / 64)) {
+        int64_t pp[FB];
+        uint2 rr[FB];
+#pragma unroll
+        for (int k = 0; k < FB; k++) {
+            const uint32_t j = j0 + (uint32_t)k * (BT / 64);
+            pp[k] = j < nlive ? ((int64_t)mylist[1 + j] << 6) + (t & 63) : ntri;
+            rr[k] = pp[k] < ntri ? ranges[pp[k]] : make_uint2(RANGE_NONE_X, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < FB; k++) {
+            if (j0 + (uint32_t)k * (BT / 64) >= nlive) break;            // wave-uniform
+            for_each_tile(unpack_box(rr[k]), (uint32_t)pp[k], [&](const PixBox& b, uint32_t prim, int tx, int ty) {
+                const uint32_t pos = atomicAdd(&cursor[ty * tiles_x + tx], 1u);
+                bins[pos] = prim | (tag_class ? size_class(b, tx, ty) << CLASS_SHIFT : 0u);
+            });
+        }
     }
 }
 

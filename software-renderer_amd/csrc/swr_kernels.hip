@@ -501,14 +501,19 @@ __device__ __forceinline__ bool group_culled(const SetupArgs& a, int64_t g) {
 // ([G][1 + per]: count, group ids) for k_fill_lds to walk the same groups in the same order.  Phase 2: one wave
 // per surviving group.  (The cull used to be a kernel of its own; a thin band's frame is bound by the host's
 // launch rate, so it moved in here.)
-template <int BT>
+// H16: two 16-bit counters per LDS word.  A workgroup's count for a tile is at most the number of primitives it owns
+// (64 * per < 65536, checked by the launcher), so a half never carries into its neighbour.  A 4K histogram is then 8 KB
+// instead of 16 KB and the workgroup fits into the LDS five resident k_raster workgroups leave free on a CU (12.5 KB)
+// instead of displacing one of them for as long as it runs.
+template <int BT, bool H16>
 __global__ __launch_bounds__(BT) void k_setup_hist(SetupArgs a, uint32_t* __restrict__ M,
                                                      uint32_t* __restrict__ live, int per, int ntiles) {
-    extern __shared__ uint32_t hist[];               // [ntiles] histogram, [per] surviving groups, [1] their count
-    uint32_t* mylist = hist + ntiles;                // (all dynamic: the kernel may ask for the whole 160 KB)
+    extern __shared__ uint32_t hist[];               // [ntiles] (or [ntiles/2]) histogram, [per] surviving groups, [1] their count
+    const int hwords = H16 ? (ntiles + 1) >> 1 : ntiles;
+    uint32_t* mylist = hist + hwords;                // (all dynamic: the kernel may ask for the whole 160 KB)
     uint32_t& nlive_s = mylist[per];
     if (threadIdx.x == 0) nlive_s = 0u;
-    for (int e = threadIdx.x; e < ntiles; e += blockDim.x) hist[e] = 0u;
+    for (int e = threadIdx.x; e < hwords; e += blockDim.x) hist[e] = 0u;
     __syncthreads();
     {
         const int64_t groups = (a.ntri + 63) >> 6;
@@ -558,12 +563,15 @@ __global__ __launch_bounds__(BT) void k_setup_hist(SetupArgs a, uint32_t* __rest
         // 34.5 us, k_fill_lds 25.7 -> 33.8 us, profiles/r02/bin_aggregate_ab.txt: the LDS resolves same-address atomics
         // faster than the wave can find its runs)
         for_each_tile(unpack_box(r), (uint32_t)p, [&](const PixBox&, uint32_t, int tx, int ty) {
-            atomicAdd(&hist[ty * tiles_x + tx], 1u);
+            const int tile = ty * tiles_x + tx;
+            if (H16) atomicAdd(&hist[tile >> 1], 1u << ((tile & 1) << 4));
+            else atomicAdd(&hist[tile], 1u);
         });
     }
     __syncthreads();
     uint32_t* row = M + (size_t)blockIdx.x * (size_t)ntiles;
-    for (int e = threadIdx.x; e < ntiles; e += blockDim.x) row[e] = hist[e];
+    for (int e = threadIdx.x; e < ntiles; e += blockDim.x)
+        row[e] = H16 ? (hist[e >> 1] >> ((e & 1) << 4)) & 0xFFFFu : hist[e];
 }
 
 // 256 threads = 16 tiles x 16 segments of the workgroup axis; a segment is ceil(G/16) rows, walked in
@@ -1687,9 +1695,11 @@ void launch_texture_to_float(const uint32_t* bgra, int64_t n, float4* out, hipSt
 // (per loaded code object): swr_context_create calls this after hipSetDevice for every device it opens.
 hipError_t prepare_device() {
     hipError_t e;
-    if ((e = hipFuncSetAttribute((const void*)k_setup_hist<BIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_setup_hist<BIN_THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_setup_hist<BIN_THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_fill_lds<BIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)k_fill_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -1701,18 +1711,30 @@ hipError_t prepare_device() {
         else hipLaunchKernelGGL(kernel, grid, block, lds, stream, __VA_ARGS__);                        \
     } while (0)
 
+// 16-bit LDS counters in the two binning walks: a workgroup's count for one tile is at most the primitives it owns
+// (k_fill_lds with 16-bit running counts in LDS and its bin positions gathered from its row of M was built too: alone
+// 23.2 -> 33.9 us, and with BOTH walks co-resident with the raster the frame went 0.096 -> 0.111 ms although k_raster
+// itself got faster, 97 -> 93 us: profiles/r02/hist16_ab.txt.  Only k_setup_hist keeps the small histogram.)
+static bool bin_h16(int per) {
+    static const bool on = !(getenv("SWR_HIST16") && getenv("SWR_HIST16")[0] == '0');
+    return on && (int64_t)per * 64 < 65536;
+}
+
 void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
     if (f.ntri <= 0) return;
     const SetupArgs a = make_setup_args(f);
     const int ntiles = f.tg.tiles_x * f.tg.tiles_y;
     if (f.plan.use_lds) {
         const int per = live_groups_per_workgroup(f.ntri, f.plan.G);
-        const size_t lds = f.plan.lds_bytes + (size_t)(per + 1) * 4;
-        if (f.plan.threads == 256)
-            hipLaunchKernelGGL(k_setup_hist<256>, dim3(f.plan.G), dim3(256), lds, s, a, f.bin_matrix, f.live, per, ntiles);
-        else
-            hipLaunchKernelGGL(k_setup_hist<BIN_THREADS>, dim3(f.plan.G), dim3(BIN_THREADS), lds, s, a, f.bin_matrix,
-                               f.live, per, ntiles);
+        const bool h16 = bin_h16(per);
+        const size_t lds = (h16 ? (size_t)((ntiles + 1) / 2) * 4 : f.plan.lds_bytes) + (size_t)(per + 1) * 4;
+        if (f.plan.threads == 256) {
+            if (h16) hipLaunchKernelGGL((k_setup_hist<256, true>), dim3(f.plan.G), dim3(256), lds, s, a, f.bin_matrix, f.live, per, ntiles);
+            else hipLaunchKernelGGL((k_setup_hist<256, false>), dim3(f.plan.G), dim3(256), lds, s, a, f.bin_matrix, f.live, per, ntiles);
+        } else {
+            if (h16) hipLaunchKernelGGL((k_setup_hist<BIN_THREADS, true>), dim3(f.plan.G), dim3(BIN_THREADS), lds, s, a, f.bin_matrix, f.live, per, ntiles);
+            else hipLaunchKernelGGL((k_setup_hist<BIN_THREADS, false>), dim3(f.plan.G), dim3(BIN_THREADS), lds, s, a, f.bin_matrix, f.live, per, ntiles);
+        }
         hipLaunchKernelGGL(k_colscan, dim3((ntiles + 15) / 16), dim3(256), 0, s, f.bin_matrix, f.plan.G, ntiles,
                            f.tile_count);
     } else {

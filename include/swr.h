@@ -205,9 +205,10 @@ int swr_target_set(swr_context* ctx, int64_t width, int64_t height,
                    int64_t row_begin, int64_t row_end);
 
 /* One frame: clear + all triangles (Renderer.swift:204-230) into the device-resident band(s).
- * Asynchronous on the context's streams; swr_sync(), swr_present_wait() or a swr_read_* completes it.  On a
- * multi-device context the call only posts the frame to the per-device threads; an error of the draw itself
- * (no scene, bad index count, ...) is then returned by the next of those blocking calls. */
+ * Asynchronous: the call validates its arguments and posts the frame to the context's helper threads, which
+ * enqueue it on the HIP streams; swr_sync(), swr_present_wait() or a swr_read_* completes it.  A HIP failure while
+ * enqueueing is returned by the next of those blocking calls; on a multi-device context the same holds for an
+ * error of the draw itself (no scene, bad index count, ...). */
 int swr_draw(swr_context* ctx, const float transform[16], uint32_t flags);
 /* Same with RenderPass.primitiveType (Renderer.swift:197, :210-219): .triangle = swr_draw;
  * .vertices plots every vertex reference as a point (Renderer.swift:295-302); .line clears only
@@ -229,8 +230,8 @@ int swr_sync(swr_context* ctx);
  *   hipMemcpyAsync per image, colour and depth in flight together on two copy streams, behind that frame's
  *   raster.  The device framebuffers are double-buffered: the next swr_draw renders into the other one, so the
  *   copy of frame N overlaps the raster of frame N+1.  Either pointer may be NULL (image not wanted; colour is
- *   skipped for SWR_FLAG_NO_COLOR frames).  A destination that is not page-locked still works but is staged
- *   through pinned 8 MiB chunks of the context and blocks the caller.
+ *   skipped for SWR_FLAG_NO_COLOR frames).  A destination that is not page-locked still works: it is staged
+ *   through pinned 8 MiB chunks by the context's helper thread (or, without helper threads, by the caller).
  * swr_present_wait(ctx): returns when every enqueued copy has landed: the pixels are host-visible.
  *
  * swr_read_color / swr_read_depth: swr_sync + the same copy of one image + wait (rows outside the band(s) are

@@ -107,3 +107,24 @@ def test_random_call_sequences(swr, oracle, monkeypatch, env, n, seed):
     for lst in pool.values():
         for a, b in lst:
             a.free(); b.free()
+
+
+@pytest.mark.parametrize("n", [1, 3])
+def test_destroy_with_frames_and_presents_in_flight(swr, oracle, n):
+    """swr_context_destroy right behind a burst of draws and an un-waited present: the helper threads are drained, the
+    streams synchronised and the page-locked image is complete (the copy was enqueued before the destroy returned)."""
+    S = swr.scenes
+    s = S.random_soup(20000, 640, 352, 0xD35, r_ndc=0.05, flags=DT, margin=1.1)
+    ci, di = swr.HostImage((s.height, s.width, 4), np.uint8), swr.HostImage((s.height, s.width), np.float32)
+    for rep in range(4):
+        ctx = swr.Context(0, device_count=n)
+        ctx.scene_upload(s.vertices, s.indices)
+        ctx.target_set(s.width, s.height)
+        for _ in range(12):
+            ctx.draw(s.transform, DT)
+        ctx.present(ci, di)
+        ctx.close()                                # no sync, no present_wait
+        rc, rd, _, code = oracle.render_scene(s)
+        assert code == 0 and np.array_equal(ci.array, rc) and di.array.tobytes() == rd.tobytes(), f"rep {rep}"
+        ci.array[:] = 0; di.array[:] = 0
+    ci.free(); di.free()

@@ -41,6 +41,7 @@
 // Float discipline: compiled with -ffp-contract=off; only + - * / in the order of the
 // reference; IEEE-correct division; the same expressions in setup, raster and resolve.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <hip/hip_ext.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -1237,7 +1238,13 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
         // have run out) every lane takes one: the owner's constants come from the LDS tables (2 x ds_read_b128 +
         // ds_read_b32), then UNIT x (weights, depth, ds_min_u64).  Dense steps are always full except the last of a
         // chunk, and there is no owner search: the unit carries its owner.
-        {
+        // Wide chunks (at least half of the chunk's triangles cover half the tile or more: walls, ground planes,
+        // screen-filling triangles): the same machinery with units of 32 pixels (SL = 3) instead of 4 — a 64-pixel row is
+        // two units = one producer step instead of six, and the consumer walks its unit in eight groups of four.  The
+        // two instantiations are chosen per chunk (wave-uniform); narrow chunks run the code they always ran.
+        auto dense = [&](auto SLc) {
+            constexpr int SL = decltype(SLc)::value;            // log2 of the 4-pixel groups per unit
+            constexpr int UPX = UNIT << SL;                     // pixels per unit
             const bool mine = have && !big;
             const int wbase = tid & ~63;
             // same-wave producers and consumers: LDS operations of one wave execute in order; the wavefront-scope
@@ -1281,7 +1288,7 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                     }
                     const int xs = lo + xprog;
                     const int left = act ? max(hi - xs + 1, 0) : 0;       // pixels of the span not yet queued
-                    const int nall = (left + UNIT - 1) / UNIT;
+                    const int nall = (left + UPX - 1) / UPX;
                     const int nu = min(nall, QMAXU);
                     static_assert(QMAXU == 3, "the prefix below adds two ballots: unit counts 0..3");
                     const unsigned long long b0 = __ballot(nu & 1), b1 = __ballot(nu & 2);
@@ -1295,9 +1302,9 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                     for (int u = 0; u < QMAXU; u++)
                         if (u < nu)
                             q[(at + (uint32_t)u) & (uint32_t)(QCAP - 1)] =
-                                ebase + ((uint32_t)(UNIT * u) << 6) + ((uint32_t)(min(UNIT, left - UNIT * u) - 1) << 17);
+                                ebase + ((uint32_t)(UPX * u) << 6) + ((uint32_t)(min(UPX, left - UPX * u) - 1) << 17);
                     const bool rowdone = nall <= QMAXU;
-                    xprog = rowdone ? 0 : xprog + UNIT * QMAXU;
+                    xprog = rowdone ? 0 : xprog + UPX * QMAXU;
                     if (act && rowdone) {
                         y += 1;
                         if (!METAL) {
@@ -1316,16 +1323,21 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                     const bool on = (uint32_t)lane < n;
                     const uint32_t e = q[(qhead + (uint32_t)lane) & (uint32_t)(QCAP - 1)];
                     const int owner = (int)(e & 63u);
-                    const int lidx0 = (int)((e >> 6) & 2047u);                       // yl * TILE_W + xl0
-                    const int xl0 = (int)((e >> 6) & 63u), yl = (int)((e >> 12) & 31u);
-                    const int nvalid = on ? (int)((e >> 17) & 3u) + 1 : 0;
-                    static_assert(TILE_W == 64 && TILE_H == 32 && UNIT <= 4, "unit entry layout");
+                    const int lidx00 = (int)((e >> 6) & 2047u);                      // yl * TILE_W + xl0
+                    const int xl00 = (int)((e >> 6) & 63u), yl = (int)((e >> 12) & 31u);
+                    const int nvalid0 = on ? (int)((e >> 17) & (uint32_t)(UPX - 1)) + 1 : 0;
+                    static_assert(TILE_W == 64 && TILE_H == 32 && UNIT == 4 && UPX <= 32, "unit entry layout: 5 bits of pixel count");
                     const uint32_t oprim = tabP[wbase + owner];
                     float4 ta = make_float4(0, 0, 0, 0), tb = make_float4(0, 0, 0, 0);
                     if (ZTEST) { ta = tabA[wbase + owner]; tb = tabB[wbase + owner]; }
                     const int cp = __float_as_int(tb.w);
-                    const int dxi = xl0 - (int)(short)(cp & 0xFFFF);                 // x - C.x of the unit's first pixel
                     const int dyi = yl - (cp >> 16);                                 // y - C.y
+#pragma unroll 1
+                    for (int sg = 0; sg < (1 << SL); sg++) {                         // the unit's groups of four pixels (one: SL == 0)
+                    if (SL > 0 && !__any(nvalid0 > UNIT * sg)) break;               // wave-uniform
+                    const int xl0 = xl00 + UNIT * sg, lidx0 = lidx00 + UNIT * sg;
+                    const int nvalid = min(max(nvalid0 - UNIT * sg, 0), UNIT);
+                    const int dxi = xl0 - (int)(short)(cp & 0xFFFF);                 // x - C.x of the group's first pixel
                     if (VAR == 2 || VAR == 5) { asm volatile("" ::"v"(ta.x), "v"(ta.y), "v"(ta.z), "v"(ta.w), "v"(tb.x), "v"(tb.y), "v"(tb.z), "v"(dxi), "v"(dyi), "v"(nvalid), "v"(lidx0), "v"(oprim)); }
                     else if (METAL) {
                         // Shaders.metal:133-161 with ta = (A0,B0,A1,B1), tb = (z1,z2,z3, .); small integer coordinates:
@@ -1391,11 +1403,19 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                         for (int qq = 0; qq < UNIT; qq++)
                             if (qq < nvalid) atomicMin(&keys[lidx0 + qq], key);
                     }
+                    }   // sg
                 }
                 qhead += n;
                 qcount -= n;
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next chunk rewrites the tables
+        };
+        {
+            // wide mode when at least half of the chunk's triangles that take the dense route are large for this tile
+            const unsigned long long dm = __ballot(have && !big);
+            const unsigned long long lg = __ballot(have && !big && large);
+            if (dm != 0ull && 2 * __popcll(lg) >= __popcll(dm)) dense(std::integral_constant<int, 3>{});
+            else dense(std::integral_constant<int, 0>{});
         }
         // the next chunk (wave-uniform): the following one when the waves split rows, else stolen from the counter
         first_chunk = false;

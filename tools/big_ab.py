@@ -8,7 +8,7 @@ sys.path.insert(0, %r)
 import swr_amd
 S = swr_amd.scenes
 for name, sc, fl in (("big 300 1080p", S.random_soup(300, 1920, 1080, 91, r_ndc=1.5, flags=1, margin=0.5), 1), ("occluded z=0.5", S.occluded_soup(z_occluder=0.5), 3),
-                 ("cfg5", S.cfg5_sponza_scale(), 1), ("cfg3", S.cfg3_bunny_scale(), 1), ("cfg4", S.cfg4_soup(), 3), ("mixed 30 big + 6k small", None, 1)):
+                 ("20k tris of ~100 px 1080p", S.random_soup(20000, 1920, 1080, 92, r_ndc=0.08, flags=1, margin=1.0), 1), ("5k tris of ~200 px 1080p", S.random_soup(5000, 1920, 1080, 93, r_ndc=0.16, flags=1, margin=1.0), 1), ("cfg5", S.cfg5_sponza_scale(), 1), ("cfg3", S.cfg3_bunny_scale(), 1), ("cfg4", S.cfg4_soup(), 3), ("mixed 30 big + 6k small", None, 1)):
     if sc is None:
         import numpy as np
         a = S.random_soup(30, 1280, 720, 31, r_ndc=1.0, flags=1, margin=0.9); b = S.random_soup(6000, 1280, 720, 32, r_ndc=0.03, flags=1, margin=1.1)

@@ -12,7 +12,13 @@ with swr_amd.Context() as ctx:
         ctx.target_set(sc.width, sc.height, r0, r1)
         for _ in range(20): ctx.draw(sc.transform, sc.flags)
         ctx.sync()
-        for rep in range(3):
+        for rep in range(3):                     # 40 draws: below the 64-frame bound on frames waiting for the helper threads
+            t0 = time.perf_counter()
+            for _ in range(40): ctx.draw(sc.transform, sc.flags)
+            t1 = time.perf_counter()
+            ctx.sync()
+            print(f"band {k} of {parts}: caller-side cost of swr_draw {1e6*(t1-t0)/40:.1f} us/frame (40 un-waited draws)", flush=True)
+        for rep in range(3):                     # 200 draws: the caller is paced by the GPU once it is 64 frames ahead
             t0 = time.perf_counter()
             for _ in range(200): ctx.draw(sc.transform, sc.flags)
             t1 = time.perf_counter()

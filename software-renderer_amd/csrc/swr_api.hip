@@ -325,7 +325,7 @@ int sync_streams(swr_context* c) {
     if (rc) return rc;
     HIP_TRY(c, hipStreamSynchronize(c->bin_stream));
     HIP_TRY(c, hipStreamSynchronize(c->stream));
-    c->synced_upto = c->frame_no;
+    c->synced_upto = c->posted;      // NOT frame_no: enqueue_frame may sync after it has numbered the frame it is about to post
     return SWR_OK;
 }
 

@@ -128,3 +128,40 @@ def test_destroy_with_frames_and_presents_in_flight(swr, oracle, n):
         assert code == 0 and np.array_equal(ci.array, rc) and di.array.tobytes() == rd.tobytes(), f"rep {rep}"
         ci.array[:] = 0; di.array[:] = 0
     ci.free(); di.free()
+
+
+@pytest.mark.parametrize("level", [1, 2])
+def test_long_timed_bursts_reuse_working_sets_correctly(swr, oracle, level):
+    """More timed frames than the 64-deep event ring, alternating two transforms, no wait: the ring is drained in the
+    middle of swr_draw (a full sync AFTER the frame has been numbered but BEFORE it is posted).  Round 2 had a bug here:
+    the sync recorded the not-yet-posted frame as complete, so the binning three frames later did not wait for its
+    raster and overwrote the working set under it.  Every presented frame is checked."""
+    S = swr.scenes
+    s = S.random_soup(60000, 1280, 704, 0x71ED, r_ndc=0.03, flags=DT, margin=1.1)
+    W, H = s.width, s.height
+    mats = []
+    for k in range(2):
+        m = np.eye(4, dtype=np.float32)
+        m[0, 0] = 0.9 - 0.2 * k; m[1, 1] = 0.8 + 0.25 * k; m[3, 0] = 0.1 * k - 0.05
+        mats.append(np.ascontiguousarray(m).reshape(16))
+    want = [oracle.render(s.vertices, s.indices, m, W, H, DT)[:2] for m in mats]
+    imgs = [(swr.HostImage((H, W, 4), np.uint8), swr.HostImage((H, W), np.float32)) for _ in range(4)]
+    with swr.Context() as ctx:
+        ctx.scene_upload(s.vertices, s.indices)
+        ctx.target_set(W, H)
+        ctx.timing_enable(level)
+        for rep in range(3):
+            shown = []
+            for k in range(150):
+                ctx.draw(mats[k & 1], DT)
+                if k in (60, 63, 66, 149):                    # around the ring drain, and the last frame
+                    ci, di = imgs[len(shown)]
+                    ctx.present(ci, di)
+                    shown.append(k & 1)
+            ctx.present_wait()
+            for (ci, di), which in zip(imgs, shown):
+                assert np.array_equal(ci.array, want[which][0]), f"rep {rep}: colour of a frame with transform {which}"
+                assert di.array.tobytes() == want[which][1].tobytes(), f"rep {rep}: depth of a frame with transform {which}"
+        ctx.timing_enable(0)
+    for a, b in imgs:
+        a.free(); b.free()

@@ -213,12 +213,18 @@ struct swr_context {
     // bin_done / ras_done are bound to the kernels they follow (hipExtLaunchKernelGGL's stop event) instead of being
     // recorded behind them: a marker packet between two kernels of a queue costs the second one ~6.5 us.  SWR_BIND_EVENTS=0: record.
     bool bind_events = true;
+    // One frame at a time (an interactive app: swr_draw, swr_sync / swr_present_wait, idle, ...) does not need the
+    // helpers: when every earlier frame is known to be complete, the frame is enqueued by the caller's thread itself,
+    // ordered by event waits on the streams — the helpers may be asleep by then, and waking two threads costs more than
+    // the two wait packets (draw -> sync of cfg4 after 5 ms of idle: 205 -> 180 us; cfg2 94 -> 70 us,
+    // profiles/r02/cold_latency.txt).  Frames drawn while others are in flight go through the helpers.  SWR_INLINE_IDLE=0: never.
+    bool inline_idle = true;
     std::atomic<uint64_t> bin_enqueued{0};      // frames whose binning (incl. the bin_done record) is on the binning stream
     std::atomic<uint64_t> ras_enqueued{0};      // frames whose raster (incl. the ras_done record) is on the raster stream
     std::atomic<int> bin_error{0};
     uint64_t posted = 0;                        // frames whose binning share has been handed to the helper (or run inline)
     static constexpr int RAS_RING = 64;          // frames whose raster share may be waiting for ras_worker; swr_draw blocks beyond that
-    struct RasJob { DeviceFrame f; hipEvent_t ev3 = nullptr, ev4 = nullptr; int si = 0; bool sort_here = false; int fb = 0; } ras_job[RAS_RING];
+    struct RasJob { DeviceFrame f; hipEvent_t ev3 = nullptr, ev4 = nullptr; int si = 0; bool sort_here = false; int fb = 0; bool paced = false; } ras_job[RAS_RING];
     // last draw (for the overflow redo and for swr_render)
     float last_m[16]{};
     uint32_t last_flags = 0;
@@ -485,7 +491,10 @@ int enqueue_frame(swr_context* c) {
     // this slot's buffers are free again once the raster of NSLOT frames ago has read them (a full sync since then
     // settles it: every non-pipelined path syncs first)
     const bool slot_wait = sb != sr && frame >= (uint64_t)swr_context::NSLOT && frame - (uint64_t)swr_context::NSLOT >= c->synced_upto;
-    auto bin_share = [c, f, si, sb, sr, frame, zero_tables, zero_bytes, e0, e1, e2, sort_on_raster_stream, slot_wait]() -> int {
+    // helpers or the caller's own thread?  (idle context: every earlier frame is complete)
+    const bool streaming = sb != sr && c->bin_worker && !(c->inline_idle && c->synced_upto == c->posted);
+    const bool paced = streaming && c->ras_worker != nullptr;      // cross-stream order by host polls instead of event waits
+    auto bin_share = [c, f, si, sb, sr, frame, zero_tables, zero_bytes, e0, e1, e2, sort_on_raster_stream, slot_wait, paced]() -> int {
         swr_context::Slot& sl = c->slot[si];
         if (slot_wait) {
             // the first event-carrying raster at or after that frame (RAS_EVERY); its event must have been bound /
@@ -496,7 +505,7 @@ int enqueue_frame(swr_context* c) {
                 if (++spins > 100000) std::this_thread::yield(); else __builtin_ia32_pause();
             swr_context::Slot& es = c->slot[ef % (uint64_t)swr_context::NSLOT];
             if (es.ras_event_frame == ef) {
-                if (c->ras_worker) { const int rc = poll_event(c, es.ras_done); if (rc) return rc; }
+                if (paced) { const int rc = poll_event(c, es.ras_done); if (rc) return rc; }
                 else HIP_TRY(c, hipStreamWaitEvent(sb, es.ras_done, 0));
             }
         }
@@ -520,9 +529,10 @@ int enqueue_frame(swr_context* c) {
     swr_context::RasJob& rj = c->ras_job[frame % swr_context::RAS_RING];
     rj.f = f; rj.ev3 = ev ? ev[3] : nullptr; rj.ev4 = ev ? ev[4] : nullptr; rj.si = si; rj.sort_here = sort_on_raster_stream;
     rj.fb = c->fb_cur;
+    rj.paced = paced;
     c->draw_pending = true;   // the pair total lands in the frame's pinned word (written by the scan)
     c->posted = frame + 1;
-    if (sb != sr && c->bin_worker) {
+    if (streaming) {
         // two threads: the helper enqueues this frame's binning while this thread enqueues the previous frame's raster
         c->bin_worker->post([c, bin_share, frame]() -> int {
             const int rc = bin_share();
@@ -569,7 +579,7 @@ int enqueue_raster_shares(swr_context* c, uint64_t upto) {
         hipStream_t sb = c->bin_stream, sr = c->stream;
         c->hp_begin_r();
         if (sb != sr) {
-            if (c->ras_worker) { const int rc = poll_event(c, sl.bin_done); if (rc) return rc; }
+            if (rj.paced) { const int rc = poll_event(c, sl.bin_done); if (rc) return rc; }
             else HIP_TRY(c, hipStreamWaitEvent(sr, sl.bin_done, 0));
         }
         c->hp_lap_r(3);
@@ -1019,6 +1029,7 @@ int create_single(int dev, swr_context** out) {
             const char* ht = getenv("SWR_HOST_THREADS");
             if (c->bin_stream_own && !(ht && ht[0] == '1')) { c->bin_worker = new Worker(); c->bin_worker->start(dev); }
             { const char* be = getenv("SWR_BIND_EVENTS"); c->bind_events = !(be && be[0] == '0'); }
+            { const char* ii = getenv("SWR_INLINE_IDLE"); c->inline_idle = !(ii && ii[0] == '0'); }
             const char* ew = getenv("SWR_EVENT_WAITS");
             if (c->bin_worker && !(ew && ew[0] == '1')) { c->ras_worker = new Worker(); c->ras_worker->start(dev); }
         }

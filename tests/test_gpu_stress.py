@@ -4,6 +4,8 @@ pipelining switches — in any order, under every stream-ordering mode.  Every i
 swr_present + swr_present_wait) is compared bit for bit with the oracle's frame for that draw.  The context runs three
 host threads and three HIP streams per band; this is the test that they never hand out a frame built
 from another frame's working set, a half-written framebuffer or a stale scene."""
+import os
+
 import numpy as np
 import pytest
 
@@ -18,9 +20,13 @@ def _mat(rng):
     return np.ascontiguousarray(m).reshape(16)
 
 
+# SWR_STRESS_SEEDS=N adds N more random sequences (seeds 100..) per band count: a longer soak, one pytest run
+_EXTRA = [(1 + 2 * (k % 2), 100 + k) for k in range(int(os.environ.get("SWR_STRESS_SEEDS", "0")))]
+
+
 @pytest.mark.parametrize("env", [{}, {"SWR_EVENT_WAITS": "1"}, {"SWR_HOST_THREADS": "1"}],
                          ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")
-@pytest.mark.parametrize("n,seed", [(1, 11), (1, 12), (1, 14), (3, 13), (2, 15)])
+@pytest.mark.parametrize("n,seed", [(1, 11), (1, 12), (1, 14), (3, 13), (2, 15)] + _EXTRA)
 def test_random_call_sequences(swr, oracle, monkeypatch, env, n, seed):
     S = swr.scenes
     for k, v in env.items():

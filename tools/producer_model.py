@@ -155,3 +155,27 @@ for a in (10, 12):
 tt = sum(np.maximum(0, pair_cols - 10 - 12 * k) for k in range(5))
 e1 = pair_rows + (pair_rows * tt / np.maximum(pair_cols, 1)).astype(np.int64)
 total_steps(np.minimum(e1 - 1, 62), "KERNEL FORMULA: min(rows + rows*T(cols)/cols - 1, 62)")
+# --- intra-tile balance: four waves, chunks heaviest first, first four static then stolen; time of a chunk in
+# "step units" = setup (5) + its producer steps + its consumer steps (units / 64 * 1.2) ---
+units_pair = pair_units[order]          # same order as pt / ps (sorted by tile, rows desc)
+cu = np.bincount(chunk_id, weights=units_pair)
+ctime = 5.0 + csteps + cu / 64.0 * 1.2
+ctile = np.zeros(chunk_id[-1] + 1, np.int64); ctile[chunk_id] = pt
+def tile_times(split_first):
+    tot_max = 0.0; tot_sum = 0.0
+    starts = np.flatnonzero(np.r_[1, np.diff(ctile)]); ends = np.r_[starts[1:], len(ctile)]
+    for a0, b0 in zip(starts, ends):
+        t = list(ctime[a0:b0])
+        if len(t) * 64 <= 128:   # row-split tiles: all waves walk every chunk
+            w = sum(5.0 + (x - 5.0) / 4 for x in t); tot_max += w; tot_sum += 4 * w; continue
+        if split_first and len(t) >= 2:
+            h = 5.0 + (t[0] - 5.0) / 2
+            t = [h, h] + t[1:]
+        waves = [0.0] * 4
+        for x in t:
+            i = int(np.argmin(waves)); waves[i] += x
+        tot_max += max(waves); tot_sum += sum(waves)
+    return tot_max, tot_sum
+for sp in (False, True):
+    mx, sm = tile_times(sp)
+    print(f"  tile schedule, heaviest chunk split over two waves = {sp}: sum of tile critical paths {mx:.0f}, busy fraction of the 4 waves {sm / (4 * mx):.3f}")

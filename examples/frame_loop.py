@@ -229,6 +229,43 @@ def run(frames: int, size: int, out: str | None, obj: str | None = None, depth_t
     return vertices, indices, results
 
 
+def run_streamed(frames: int, size: int, obj: str | None = None, depth_test: bool = False, time0: float = 0.0,
+                 device_count: int = 1, on_frame=None):
+    """The same loop the way a host that wants every frame should drive it: two page-locked
+    image sets alternate; frame k is being copied to the host (swr_present, asynchronous, every band of a multi-GPU
+    context into its rows of the ONE image) while frame k+1 is drawn; the host touches frame k only after
+    swr_present_wait.  `on_frame(k, colour, depth)` sees the host images (valid until the next but one present).
+    Returns the frames (copies)."""
+    vertices, indices = load_mesh(obj) if obj else sphere_mesh()
+    flags = S.FLAG_DEPTH_TEST if depth_test else 0
+    sets = [(swr_amd.HostImage((size, size, 4), np.uint8), swr_amd.HostImage((size, size), np.float32)) for _ in range(2)]
+    results = []
+
+    def deliver(k):
+        c, d = sets[k & 1]
+        if on_frame:
+            on_frame(k, c.array, d.array)
+        results.append((c.array.copy(), d.array.copy()))
+
+    with swr_amd.Context(0, device_count=device_count) as ctx:
+        ctx.scene_upload(vertices, indices)
+        ctx.target_set(size, size)
+        time = time0
+        for k in range(frames):
+            ctx.draw(S.app_transform(time), flags)
+            ctx.present(*sets[k & 1])                   # returns at once
+            if k >= 1:
+                ctx.present_wait()                      # every enqueued copy has landed: frame k-1 (and k) are host-visible
+                deliver(k - 1)
+            time += 1.0 / 60.0
+        ctx.present_wait()
+        if frames:
+            deliver(frames - 1)
+    for c, d in sets:
+        c.free(); d.free()
+    return results
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=4)
@@ -237,7 +274,13 @@ if __name__ == "__main__":
     ap.add_argument("--obj", default=None, help="Wavefront OBJ mesh")
     ap.add_argument("--ply", default=None, help="Stanford PLY mesh (ascii or binary little endian)")
     ap.add_argument("--depth-test", action="store_true")
+    ap.add_argument("--stream", action="store_true", help="asynchronous presents into two page-locked image sets")
+    ap.add_argument("--gpus", type=int, default=1, help="bands / GPUs of the one context (with --stream)")
     a = ap.parse_args()
+    if a.stream:
+        res = run_streamed(a.frames, a.size, a.ply or a.obj, a.depth_test, device_count=a.gpus)
+        print(f"{a.frames} frames streamed, coverage per frame: {[round(float((c[..., 3] == 255).mean()), 4) for c, _ in res]}")
+        sys.exit(0)
     _, idx, res = run(a.frames, a.size, a.out, a.ply or a.obj, a.depth_test)
     cov = [(c[..., 3] == 255).mean() for c, _, _ in res]
     print(f"{a.frames} frames, {idx.size // 3} triangles, coverage per frame: {[round(float(x), 4) for x in cov]}")

@@ -423,6 +423,14 @@ def test_headless_frame_loop_and_obj_loader(oracle, swr, tmp_path):
     assert i.tolist() == [0, 1, 2, 0, 2, 3] and v.shape == (4, 8)
     rc_c, rc_d, _, _ = oracle.render(v, i, frames[0][2], 64, 64, 0)
     assert_same(frames[0][0], frames[0][1], rc_c, rc_d, "obj quad")
+    # the same loop with asynchronous presents into two page-locked image sets, on one band and on three
+    _, _, ref = fl.run(5, 192, None, depth_test=True)
+    for n in (1, 3):
+        seen = []
+        streamed = fl.run_streamed(5, 192, depth_test=True, device_count=n, on_frame=lambda k, c, d: seen.append(k))
+        assert seen == [0, 1, 2, 3, 4]
+        for k, ((c, d), (rc, rd, _)) in enumerate(zip(streamed, ref)):
+            assert_same(c, d, rc, rd, f"streamed frame {k} on {n} band(s)")
 
 
 # ---- the Metal path's rules: SWR_FLAG_METAL_RULES -------------------------

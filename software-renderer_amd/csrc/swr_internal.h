@@ -86,6 +86,8 @@ struct DeviceFrame {
     uint32_t* tile_start;          // [tiles+1] exclusive scan of tile_count
     uint32_t* counters;            // [CNT_WORDS]
     uint32_t* host_counters;       // device-visible address of the pinned host copy
+    uint32_t* host_max;            // pinned host word: entries of the frame's fullest bin (written by k_fill_lds; may be NULL)
+    int32_t skip_sort;             // 1: no k_sort_bins for this frame (every bin of the previous frames fitted two chunks)
     uint32_t* tile_cursor;         // [tiles] running fill position (starts as tile_start)
     uint2* ranges;                 // [ntri] band-clipped pixel bbox (x0|x1<<16, y0|y1<<16, y band-relative)
     uint32_t* bins;                // [capacity] primitive ids grouped by tile

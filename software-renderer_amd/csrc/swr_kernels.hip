@@ -622,7 +622,7 @@ __global__ __launch_bounds__(BT) void k_fill_lds(const uint2* __restrict__ range
                                                    uint32_t* __restrict__ host_counters,
                                                    uint32_t* __restrict__ bins, uint32_t capacity,
                                                    const uint32_t* __restrict__ live, int gper,
-                                                   int ntiles, int tiles_x, int tag_class) {
+                                                   int ntiles, int tiles_x, int tag_class, uint32_t* __restrict__ host_max) {
     extern __shared__ uint32_t lds[];
     uint32_t* cursor = lds;             // [ntiles]
     uint32_t* part = lds + ntiles;      // [BT]
@@ -633,8 +633,9 @@ __global__ __launch_bounds__(BT) void k_fill_lds(const uint2* __restrict__ range
     __syncthreads();
     const int per = (ntiles + BT - 1) / BT;
     const int sb = t * per, se = min(sb + per, ntiles);
-    uint32_t sum = 0;
-    for (int i = sb; i < se; i++) sum += cursor[i];
+    uint32_t sum = 0, mx = 0;
+    for (int i = sb; i < se; i++) { sum += cursor[i]; mx = max(mx, cursor[i]); }
+    if (blockIdx.x == 0 && t == 0) part[BT / 64 + 1] = 0u;
     // exclusive prefix of the per-thread sums: a DPP scan inside every wave, then wave 0 scans the wave totals
     // (two barriers; the Hillis-Steele ladder over LDS this replaces took 2 log2(BT) = 20)
     static_assert(BT % 64 == 0 && BT / 64 <= 64, "one wave scans the wave totals");
@@ -651,10 +652,12 @@ __global__ __launch_bounds__(BT) void k_fill_lds(const uint2* __restrict__ range
     const uint32_t total = part[BT / 64];
     uint32_t run = part[t >> 6] + incl - sum;
     for (int i = sb; i < se; i++) { const uint32_t c = cursor[i]; cursor[i] = run; run += c; }
+    if (blockIdx.x == 0 && mx) atomicMax(&part[BT / 64 + 1], mx);      // the fullest bin of the frame (for the host: see launch_sort_bins)
     __syncthreads();
     if (blockIdx.x == 0) {
         for (int e = t; e < ntiles; e += BT) tile_start[e] = cursor[e];
         if (t == 0) {
+            if (host_max) *host_max = part[BT / 64 + 1];
             tile_start[ntiles] = total;
             counters[CNT_PAIRS] = total;                  // read by k_sort_bins / k_raster
             counters[CNT_OVERFLOW] = total > capacity ? 1u : 0u;
@@ -1004,7 +1007,9 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
     const bool overflow = a.counters[CNT_PAIRS] > a.capacity;
     const uint32_t b0 = overflow ? 0u : a.tile_start[tile];
     const uint32_t b1 = overflow ? 0u : a.tile_start[tile + 1];
-    const uint32_t m = b1 - b0;   // bin already sorted by size class (k_sort_bins), heaviest first
+    const uint32_t m = b1 - b0;   // bin sorted by size class (k_sort_bins), heaviest first — unless the host skipped the sort
+    // (sparse frames, launch_sort_bins): the entries then still carry k_fill_lds's class tag
+    const uint32_t bin_mask = a.tag_class ? (1u << CLASS_SHIFT) - 1u : 0xFFFFFFFFu;
 
     // the gather chain of the first batch (bin entry -> record) is issued before the LDS init so
     // that its latency overlaps the init and the barrier
@@ -1037,7 +1042,7 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
     const uint32_t slot0 = chunk * csz + (uint32_t)lane;
     const bool have0 = (uint32_t)lane < csz && slot0 < m;
     if (have0 && VAR != 9 && VAR != 11) {
-        prim_pre = a.bins[b0 + slot0];
+        prim_pre = a.bins[b0 + slot0] & bin_mask;
         q0_pre = reinterpret_cast<const int4*>(a.geo + prim_pre)[0];
         q1_pre = reinterpret_cast<const float4*>(a.geo + prim_pre)[1];
     }
@@ -1077,7 +1082,7 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             int4 q0 = q0_pre;
             float4 q1 = q1_pre;
             if (!first_chunk) {
-                prim = a.bins[b0 + e];
+                prim = a.bins[b0 + e] & bin_mask;
                 q0 = reinterpret_cast<const int4*>(a.geo + prim)[0];
                 q1 = reinterpret_cast<const float4*>(a.geo + prim)[1];
             }
@@ -1779,11 +1784,11 @@ bool launch_fill(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
         if (f.plan.threads == 256)
             SWR_LAUNCH(stop, k_fill_lds<256>, dim3(f.plan.G), dim3(256), (uint32_t)(f.plan.lds_bytes + 4 * 256), s,
                        (const uint2*)f.ranges, f.ntri, (const uint32_t*)f.bin_matrix, (const uint32_t*)f.tile_count, f.tile_start,
-                       f.counters, f.host_counters, f.bins, f.capacity, (const uint32_t*)f.live, per, ntiles, (int)f.tg.tiles_x, tagged);
+                       f.counters, f.host_counters, f.bins, f.capacity, (const uint32_t*)f.live, per, ntiles, (int)f.tg.tiles_x, tagged, f.host_max);
         else
             SWR_LAUNCH(stop, k_fill_lds<BIN_THREADS>, dim3(f.plan.G), dim3(BIN_THREADS), (uint32_t)(f.plan.lds_bytes + 4 * BIN_THREADS), s,
                        (const uint2*)f.ranges, f.ntri, (const uint32_t*)f.bin_matrix, (const uint32_t*)f.tile_count, f.tile_start,
-                       f.counters, f.host_counters, f.bins, f.capacity, (const uint32_t*)f.live, per, ntiles, (int)f.tg.tiles_x, tagged);
+                       f.counters, f.host_counters, f.bins, f.capacity, (const uint32_t*)f.live, per, ntiles, (int)f.tg.tiles_x, tagged, f.host_max);
     } else {
         const unsigned blocks = (unsigned)((f.ntri + 255) / 256);
         hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, s, f.ranges, f.ntri, f.tile_cursor, f.counters,
@@ -1795,7 +1800,7 @@ bool launch_fill(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
 
 bool launch_sort_bins(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     const unsigned tiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
-    if (f.ntri <= 0 || tiles == 0) return false;
+    if (f.ntri <= 0 || tiles == 0 || f.skip_sort) return false;
     SWR_LAUNCH(stop, k_sort_bins, dim3(tiles), dim3(SORT_THREADS), 0, s, f.bins, (const uint32_t*)f.tile_start,
                (const uint32_t*)f.counters, f.capacity, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
     return stop != nullptr;

@@ -17,12 +17,13 @@
 //                                     (no global atomics anywhere; k_setup_bin / k_scan / k_fill are the
 //                                     global-atomic fallback for tile tables that do not fit LDS)
 //   k_sort_bins   1 workgroup / tile: counting sort of the bin by size class (rows inside the tile)
-//   k_raster      1 workgroup / tile: 64-bit visibility keys of the tile live in LDS.  lane = triangle
-//                                     walks the rows of its own triangle; the spans of a row step are
-//                                     cut into 4-pixel units, prefix-summed across the wave and dealt
-//                                     out densely, lane = unit: owner found by a marker scatter + DPP
-//                                     max-scan, its constants from an LDS table, 4 x (weights, depth,
-//                                     ds_min_u64).  Resolve: key -> winning primitive -> barycentric
+//   k_raster      1 workgroup / tile: 64-bit visibility keys of the tile live in LDS.  Producer, lane =
+//                                     triangle: two integer edge steppers (a DDA of Renderer.interpolate) give
+//                                     the span of the lane's next row; ONE ring entry per span (owner lane, x,
+//                                     y, length), placed by a ballot + v_mbcnt prefix.  Consumer, lane = entry:
+//                                     the owner's constants from an LDS table, 4 x (weights, depth, ds_min_u64)
+//                                     for the first four pixels of the span; the rest of a longer span goes
+//                                     back into the ring.  Resolve: key -> winning primitive -> barycentric
 //                                     colour -> fragment_shader -> one 16-B/lane framebuffer store per
 //                                     4 pixels (clear fused: HBM sees each pixel exactly once).
 //   k_raster<.., METAL>             : the same frame under the Metal path's rules (SWR_FLAG_METAL_RULES)
@@ -389,7 +390,7 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p, c
 #endif
 constexpr int BIG_AREA = SWR_BIG_AREA;
 constexpr int LARGE_AREA = TILE_W * TILE_H / 2;   // clipped bbox area from which a triangle counts as large for its tile ...
-constexpr int LARGE_MAX = 2;                      // ... and goes the cooperative way if the chunk has at most this many   // clipped bbox area above which a triangle is walked by the whole wave (never: the dense path handles any span)
+constexpr int LARGE_MAX = 2;                      // ... and goes the cooperative way if the chunk has at most this many
 constexpr uint32_t CLASS_SHIFT = 26;
 constexpr uint32_t CLASS_BIG = 32;
 constexpr int NUM_CLASSES = 33;
@@ -972,10 +973,9 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
     float4* const tabB = tabAB + RASTER_THREADS;   //                            za, zb, zc, (C.x - X0) | (C.y - Y0) << 16
     uint32_t* const slots = reinterpret_cast<uint32_t*>(tabAB);   // resolve only (see below)
     __shared__ uint32_t tabP[RASTER_THREADS]; //                            original primitive index (the key's low word)
-    // per wave: ring of 4-pixel work units waiting for a lane.  entry = owner lane | xl0 << 6 | yl << 12 | (pixels-1) << 17
-    constexpr int QMAXU = 3;                  // units one lane may queue per row step (wider spans take another step)
-    constexpr int QCAP = 256;                 // >= 63 left over + 64 lanes x QMAXU
-    static_assert(63 + 64 * QMAXU <= QCAP && (QCAP & (QCAP - 1)) == 0, "unit ring size");
+    // per wave: ring of spans waiting for a lane.  entry = owner lane | xl << 6 | yl << 12 | (pixels - 1) << 17.
+    // At most 63 entries wait when a producer step adds up to 64; a consumer step pops n and pushes back at most n.
+    constexpr int QCAP = 128;
     __shared__ uint32_t queue[RASTER_THREADS / 64][QCAP];
     __shared__ unsigned long long keys[TILE_W * TILE_H];
     // after the last chunk the per-triangle tables are dead: the resolve keeps the winners' stream slots there
@@ -1236,20 +1236,23 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                 }
             }
         }
-        // ---- dense phase: lane = triangle for the row walk, lane = 4-pixel unit for the pixel work ------------------
-        // Producer: every lane steps through the rows of ITS OWN (small) triangle; the span of a row is cut into
-        // units of UNIT consecutive pixels and the units are appended to the wave's ring in LDS (exclusive prefix of
-        // the unit counts over the lanes from two ballots).  Consumer: whenever 64 units are waiting (or the rows
-        // have run out) every lane takes one: the owner's constants come from the LDS tables (2 x ds_read_b128 +
-        // ds_read_b32), then UNIT x (weights, depth, ds_min_u64).  Dense steps are always full except the last of a
-        // chunk, and there is no owner search: the unit carries its owner.
+        // ---- dense phase: lane = triangle for the row walk, lane = span for the pixel work -------------------------
+        // Producer: every lane steps through the rows of ITS OWN (small) triangle and appends ONE entry per non-empty
+        // span to the wave's ring in LDS (owner lane | x | y | length - 1; its position is the lane's rank in one
+        // ballot).  There is no per-row limit: a row step never has to be repeated for a wide span.
+        // Consumer: whenever 64 entries wait (or the rows have run out) every lane takes one: the owner's constants come
+        // from the LDS tables (2 x ds_read_b128 + ds_read_b32), then UNIT x (weights, depth, ds_min_u64) for the first
+        // UPX pixels of the span; what is left of a longer span goes back into the ring as a new entry (same owner,
+        // x advanced), so consumer steps stay full while the rows last.  Tail of a chunk (fewer than 64 entries, no
+        // rows left): an entry is shared by 64 / pow2(entries) lanes, lane group j taking the pixels [j UPX, (j + 1) UPX),
+        // so the last long spans do not trickle out four pixels per step.
         // Wide chunks (at least half of the chunk's triangles cover half the tile or more: walls, ground planes,
-        // screen-filling triangles): the same machinery with units of 32 pixels (SL = 3) instead of 4 — a 64-pixel row is
-        // two units = one producer step instead of six, and the consumer walks its unit in eight groups of four.  The
-        // two instantiations are chosen per chunk (wave-uniform); narrow chunks run the code they always ran.
+        // screen-filling triangles): the same machinery with UPX = 32 pixels per visit (SL = 3) instead of 4 — the
+        // consumer walks its share in eight groups of four and a 64-pixel row is two visits.  The two instantiations
+        // are chosen per chunk (wave-uniform).
         auto dense = [&](auto SLc) {
-            constexpr int SL = decltype(SLc)::value;            // log2 of the 4-pixel groups per unit
-            constexpr int UPX = UNIT << SL;                     // pixels per unit
+            constexpr int SL = decltype(SLc)::value;            // log2 of the 4-pixel groups per visit
+            constexpr int UPX = UNIT << SL;                     // pixels of a span one lane handles per visit
             const bool mine = have && !big;
             const int wbase = tid & ~63;
             // same-wave producers and consumers: LDS operations of one wave execute in order; the wavefront-scope
@@ -1262,87 +1265,60 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             tabP[tid] = t.prim;
             int y = mine ? ya : 1;
             const int ye = mine ? yb : 0;
-            int xprog = 0;                      // pixels of the current row's span already queued (spans wider than QMAXU units)
             uint32_t qhead = 0u, qcount = 0u;   // wave-uniform
             uint32_t* const q = queue[tid >> 6];
+            // ring entry = owner lane | xl << 6 | yl << 12 | (pixels - 1) << 17, xl / yl tile-local
+            static_assert(TILE_W == 64 && TILE_H == 32 && UNIT == 4, "ring entry layout: 6 + 6 + 5 + 6 bits");
+            uint32_t ebase = (uint32_t)lane | ((uint32_t)((y - Y0) & (TILE_H - 1)) << 12);
             // The two chains of draw(triangle:) (:276-277) as row steppers.  Left chain [S0,S1,S2]: the segment the
             // first row of the tile falls into, switched to [S1,S2] at the row y == S1.y (:469-475); right chain [S0,S2].
+            // At y == S2.y the interpolant returns S2.x (:469-471): the stepper of [S1,S2] arrives there by itself
+            // (D * dy / dy = D exactly), except when S1.y == S2.y, where that segment is never interpolated — it then
+            // starts (and stays) at S2.x.
             EdgeStep eL = {0, 0, 0, 0, 0, 1}, eK = eL, eR = eL;
-            const int s1y = t.ch.s1y, s2y = t.ch.s2y, s2x = t.ch.s2x;
+            const int s1y = t.ch.s1y;
             if (!METAL && mine) {
                 float rc0, rc1, rcr;
                 EdgeStep e0;
+                const int k1x = t.ch.s1y == t.ch.s2y ? t.ch.s2x : t.ch.s1x;
                 edge_consts(t.ch.s0x, t.ch.s0y, t.ch.s1x, t.ch.s1y, e0, rc0);
-                edge_consts(t.ch.s1x, t.ch.s1y, t.ch.s2x, t.ch.s2y, eK, rc1);
+                edge_consts(k1x, t.ch.s1y, t.ch.s2x, t.ch.s2y, eK, rc1);
                 edge_consts(t.ch.s0x, t.ch.s0y, t.ch.s2x, t.ch.s2y, eR, rcr);
                 const bool in1 = y >= s1y;                       // the tile starts at or below the kink
                 eL = in1 ? eK : e0;
-                edge_jump(in1 ? t.ch.s1x : t.ch.s0x, in1 ? t.ch.s2x : t.ch.s1x, y - (in1 ? t.ch.s1y : t.ch.s0y), in1 ? rc1 : rc0, eL);
+                edge_jump(in1 ? k1x : t.ch.s0x, in1 ? t.ch.s2x : t.ch.s1x, y - (in1 ? t.ch.s1y : t.ch.s0y), in1 ? rc1 : rc0, eL);
                 edge_jump(t.ch.s0x, t.ch.s2x, y - t.ch.s0y, rcr, eR);
             }
-            for (;;) {
-                while (VAR != 4 && VAR != 10 && qcount < 64u && __any(y <= ye)) {
-                    const bool act = y <= ye;
-                    int lo = 0, hi = -1;
-                    if (METAL) {
-                        if (act) { lo = max(t.ch.s0x, X0); hi = min(t.ch.s2x, X1); }   // every ROI row spans the ROI's x-range
-                    } else {
-                        const int L = y >= s2y ? s2x : eL.X;     // :469-480: at and below S2.y the left chain is S2.x
-                        lo = max(min(L, eR.X), X0);              // :278-280 swap, then the tile's scissor
-                        hi = min(max(L, eR.X), X1);
-                    }
-                    const int xs = lo + xprog;
-                    const int left = act ? max(hi - xs + 1, 0) : 0;       // pixels of the span not yet queued
-                    const int nall = (left + UPX - 1) / UPX;
-                    const int nu = min(nall, QMAXU);
-                    static_assert(QMAXU == 3, "the prefix below adds two ballots: unit counts 0..3");
-                    const unsigned long long b0 = __ballot(nu & 1), b1 = __ballot(nu & 2);
-                    const uint32_t pre =
-                        __builtin_amdgcn_mbcnt_hi((uint32_t)(b0 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b0, 0u)) +
-                        2u * __builtin_amdgcn_mbcnt_hi((uint32_t)(b1 >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b1, 0u));
-                    const uint32_t T = (uint32_t)__popcll(b0) + 2u * (uint32_t)__popcll(b1);
-                    const uint32_t ebase = (uint32_t)lane | ((uint32_t)(xs - X0) << 6) | ((uint32_t)(y - Y0) << 12);
-                    const uint32_t at = qhead + qcount + pre;
-#pragma unroll
-                    for (int u = 0; u < QMAXU; u++)
-                        if (u < nu)
-                            q[(at + (uint32_t)u) & (uint32_t)(QCAP - 1)] =
-                                ebase + ((uint32_t)(UPX * u) << 6) + ((uint32_t)(min(UPX, left - UPX * u) - 1) << 17);
-                    const bool rowdone = nall <= QMAXU;
-                    xprog = rowdone ? 0 : xprog + UPX * QMAXU;
-                    if (act && rowdone) {
-                        y += 1;
-                        if (!METAL) {
-                            edge_next_row(eL);
-                            edge_next_row(eR);
-                            if (y == s1y) eL = eK;               // the kink: [S1,S2] starts at its first point
-                        }
-                    }
-                    qcount += T;
-                }
-                if (qcount == 0u) break;
-                const uint32_t n = min(qcount, 64u);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-                if (VAR == 3) { qhead += n; qcount -= n; continue; }
-                {
-                    const bool on = (uint32_t)lane < n;
-                    const uint32_t e = q[(qhead + (uint32_t)lane) & (uint32_t)(QCAP - 1)];
-                    const int owner = (int)(e & 63u);
-                    const int lidx00 = (int)((e >> 6) & 2047u);                      // yl * TILE_W + xl0
-                    const int xl00 = (int)((e >> 6) & 63u), yl = (int)((e >> 12) & 31u);
-                    const int nvalid0 = on ? (int)((e >> 17) & (uint32_t)(UPX - 1)) + 1 : 0;
-                    static_assert(TILE_W == 64 && TILE_H == 32 && UNIT == 4 && UPX <= 32, "unit entry layout: 5 bits of pixel count");
-                    const uint32_t oprim = tabP[wbase + owner];
-                    float4 ta = make_float4(0, 0, 0, 0), tb = make_float4(0, 0, 0, 0);
-                    if (ZTEST) { ta = tabA[wbase + owner]; tb = tabB[wbase + owner]; }
-                    const int cp = __float_as_int(tb.w);
-                    const int dyi = yl - (cp >> 16);                                 // y - C.y
+            auto rank_of = [](unsigned long long m) {
+                return __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+            };
+            // One consumer step.  TAIL = false: 64 entries, lane = entry.  TAIL = true: the qcount < 64 entries that are
+            // left, each shared by 64 >> sh lanes.
+            auto consume = [&](auto TAILc) {
+                constexpr bool TAIL = decltype(TAILc)::value;
+                const uint32_t n = TAIL ? qcount : 64u;
+                const int sh = TAIL ? (n <= 1u ? 0 : 32 - __builtin_clz(n - 1u)) : 6;     // 1 << sh >= n (wave-uniform)
+                const uint32_t idx = TAIL ? (uint32_t)lane & ((1u << sh) - 1u) : (uint32_t)lane;
+                const int off = TAIL ? (lane >> sh) * UPX : 0;                            // first pixel of this lane's share
+                const int visit = (64 >> sh) * UPX;                                       // pixels of the span handled by this step
+                const uint32_t e = q[(qhead + idx) & (uint32_t)(QCAP - 1)];
+                const int len = (int)((e >> 17) & 63u) + 1;
+                const bool on = !TAIL || (idx < n && off < len);
+                const int owner = (int)(e & 63u);
+                const int lidx00 = (int)((e >> 6) & 2047u) + off;                // yl * TILE_W + xl
+                const int xl00 = (int)((e >> 6) & 63u) + off, yl = (int)((e >> 12) & 31u);
+                const int nvalid0 = on ? min(len - off, UPX) : 0;
+                const uint32_t oprim = tabP[wbase + owner];
+                float4 ta = make_float4(0, 0, 0, 0), tb = make_float4(0, 0, 0, 0);
+                if (ZTEST) { ta = tabA[wbase + owner]; tb = tabB[wbase + owner]; }
+                const int cp = __float_as_int(tb.w);
+                const int dyi = yl - (cp >> 16);                                 // y - C.y
 #pragma unroll 1
-                    for (int sg = 0; sg < (1 << SL); sg++) {                         // the unit's groups of four pixels (one: SL == 0)
-                    if (SL > 0 && !__any(nvalid0 > UNIT * sg)) break;               // wave-uniform
+                for (int sg = 0; sg < (1 << SL); sg++) {                         // the visit's groups of four pixels (one: SL == 0)
+                    if (SL > 0 && !__any(nvalid0 > UNIT * sg)) break;           // wave-uniform
                     const int xl0 = xl00 + UNIT * sg, lidx0 = lidx00 + UNIT * sg;
                     const int nvalid = min(max(nvalid0 - UNIT * sg, 0), UNIT);
-                    const int dxi = xl0 - (int)(short)(cp & 0xFFFF);                 // x - C.x of the group's first pixel
+                    const int dxi = xl0 - (int)(short)(cp & 0xFFFF);             // x - C.x of the group's first pixel
                     if (VAR == 2 || VAR == 5) { asm volatile("" ::"v"(ta.x), "v"(ta.y), "v"(ta.z), "v"(ta.w), "v"(tb.x), "v"(tb.y), "v"(tb.z), "v"(dxi), "v"(dyi), "v"(nvalid), "v"(lidx0), "v"(oprim)); }
                     else if (METAL) {
                         // Shaders.metal:133-161 with ta = (A0,B0,A1,B1), tb = (z1,z2,z3, .); small integer coordinates:
@@ -1408,10 +1384,47 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                         for (int qq = 0; qq < UNIT; qq++)
                             if (qq < nvalid) atomicMin(&keys[lidx0 + qq], key);
                     }
-                    }   // sg
-                }
+                }   // sg
+                // the rest of a span longer than this visit goes back into the ring (behind everything that waits)
+                const bool more = (!TAIL || (lane >> sh) == 0) && (!TAIL || idx < n) && len > visit;
+                const unsigned long long mb = __ballot(more);
+                if (more)
+                    q[(qhead + qcount + rank_of(mb)) & (uint32_t)(QCAP - 1)] = e + ((uint32_t)visit << 6) - ((uint32_t)visit << 17);
                 qhead += n;
-                qcount -= n;
+                qcount = qcount - n + (uint32_t)__popcll(mb);
+            };
+            for (;;) {
+                while (VAR != 4 && VAR != 10 && qcount < 64u && __any(y <= ye)) {
+                    const bool act = y <= ye;
+                    int lo, hi;
+                    if (METAL) {
+                        lo = max(t.ch.s0x, X0); hi = min(t.ch.s2x, X1);      // every ROI row spans the ROI's x-range
+                    } else {
+                        lo = max(min(eL.X, eR.X), X0);                       // :278-280 swap, then the tile's scissor
+                        hi = min(max(eL.X, eR.X), X1);
+                    }
+                    const bool put = act && lo <= hi;
+                    const unsigned long long pb = __ballot(put);
+                    if (put)
+                        q[(qhead + qcount + rank_of(pb)) & (uint32_t)(QCAP - 1)] =
+                            ebase + ((uint32_t)(lo - X0) << 6) + ((uint32_t)(hi - lo) << 17);
+                    if (act) {
+                        y += 1;
+                        ebase += 1u << 12;
+                        if (!METAL) {
+                            edge_next_row(eL);
+                            edge_next_row(eR);
+                            if (y == s1y) eL = eK;               // the kink: [S1,S2] starts at its first point
+                        }
+                    }
+                    qcount += (uint32_t)__popcll(pb);
+                }
+                if (qcount == 0u) break;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                if (VAR == 3) { const uint32_t n = min(qcount, 64u); qhead += n; qcount -= n; continue; }
+                if (qcount >= 64u) consume(std::false_type{});
+                else consume(std::true_type{});
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next chunk rewrites the tables
         };

@@ -187,11 +187,25 @@ struct swr_context {
     uint64_t frame_no = 0;
     uint64_t synced_upto = 0;           // every frame below this has completed (full stream sync seen by the caller)
     int last_slot = 0;
-    uint32_t capacity = 0;
+    uint32_t capacity = 0;              // exact bins: (triangle,tile) pairs every slot's `bins` holds
+    // Fixed-stride bins (k_bin: ONE binning launch per frame): tile t owns bins[t * cap_tile, (t + 1) * cap_tile).  The
+    // per-tile fill counters live in four rotating blocks (frame % 4) while the working sets rotate by three: k_bin of
+    // frame N zeroes the block of frame N + 1, which was last read by the raster of frame N - 3 — the raster whose
+    // completion lets the binning of frame N start.
+    static constexpr int NFILL = 4;
+    static_assert(NFILL == NSLOT + 1, "k_bin(N) zeroes the fill block of frame N + 1: its last reader must be the raster of frame N - NSLOT");
+    DevBuf fillbuf[NFILL];              // [CNT_WORDS counters][tiles fills]
+    bool fill_dirty[NFILL] = {};        // block was used and nothing has zeroed it since (then the frame memsets it first)
+    uint32_t cap_tile = 0;              // entries per tile region
+    bool fixed_mode = false;            // frames are binned by k_bin (else: exact-size bins, four kernels)
+    bool fixed_allowed = true;          // false once a tile of this scene / target needed more than the fixed path can give
+    size_t bins_entries = 0;            // entries every slot's `bins` holds
 
     // Pinned, device-mapped words.  h_pairs[f % PAIR_RING] receives the (triangle,tile) pair total of frame f from
     // the binning kernels (no D2H copy, no host sync per frame); a whole burst of un-waited frames can be checked
     // for bin overflow afterwards.  h_misc is the upload's index-check word.
+    // (Fixed-stride bins: words [PAIR_RING + 1, 2 PAIR_RING + 1) receive the LARGEST tile fill of frame f — the overflow
+    // test there is per tile region.)
     static constexpr int PAIR_RING = 256;
     uint32_t* h_pairs = nullptr;
     uint32_t* h_pairs_dev = nullptr;
@@ -302,11 +316,19 @@ int ensure(swr_context* c, DevBuf& b, size_t bytes) {
     return SWR_OK;
 }
 
-int ensure_capacity(swr_context* c, uint32_t cap) {
-    if (cap <= c->capacity) return SWR_OK;
+int ensure_bins(swr_context* c, size_t entries) {
+    if (entries <= c->bins_entries) return SWR_OK;
     int rc;
     for (auto& sl : c->slot)
-        if ((rc = ensure(c, sl.bins, (size_t)cap * 4))) return rc;
+        if ((rc = ensure(c, sl.bins, entries * 4))) return rc;
+    c->bins_entries = entries;
+    return SWR_OK;
+}
+
+int ensure_capacity(swr_context* c, uint32_t cap) {
+    if (cap <= c->capacity) return SWR_OK;
+    const int rc = ensure_bins(c, cap);
+    if (rc) return rc;
     c->capacity = cap;
     return SWR_OK;
 }
@@ -344,6 +366,39 @@ int sync_copies(swr_context* c) {
 
 inline int tiles_of(const Target& t) { return t.tiles_x * t.tiles_y; }
 inline uint32_t& pair_word(swr_context* c, uint64_t frame) { return c->h_pairs[frame % swr_context::PAIR_RING]; }
+inline uint32_t& fill_word(swr_context* c, uint64_t frame) { return c->h_pairs[swr_context::PAIR_RING + 1 + frame % swr_context::PAIR_RING]; }
+
+// Size the bins for the scene / target pair (both known; every stream idle).  Fixed-stride bins where k_bin can be used:
+// a first guess of six times the mean load per tile (the host grows it when a frame overflows), exact bins otherwise.
+int size_bins(swr_context* c) {
+    if (!c->has_scene || !c->has_target) return SWR_OK;
+    const int tiles = tiles_of(c->tg);
+    const int64_t ntri = c->ni / 3;
+    const char* bm = getenv("SWR_BIN_MODE");                  // "exact": the four-kernel path with exact-size bins (tests, tools)
+    const bool no_fixed = bm && bm[0] == 'e';
+    const uint32_t cmax = (c->fixed_allowed && !no_fixed) ? fixed_cap_max(ntri, tiles) : 0u;
+    int rc;
+    if (cmax) {
+        // a primitive enters a tile's region at most once, so a region of `ntri` entries can never overflow: small scenes
+        // get that; large ones six times the mean load of a tile, at least 4096 entries
+        uint64_t want = std::max<uint64_t>(std::max<uint64_t>(64, (uint64_t)(6 * ntri / tiles)), (uint64_t)std::min<int64_t>(ntri, 4096));
+        want = std::min<uint64_t>((want + 63) & ~63ull, cmax);
+        if (!c->fixed_mode || c->cap_tile < want || c->cap_tile > cmax) c->cap_tile = (uint32_t)want;   // a grown region survives a new transform
+        if ((rc = ensure_bins(c, (size_t)tiles * c->cap_tile))) return rc;
+        const size_t fb = (size_t)(CNT_WORDS + tiles) * 4;
+        for (int k = 0; k < swr_context::NFILL; k++) {
+            if ((rc = ensure(c, c->fillbuf[k], fb))) return rc;
+            HIP_TRY(c, hipMemsetAsync(c->fillbuf[k].p, 0, c->fillbuf[k].bytes, c->stream));
+            c->fill_dirty[k] = false;
+        }
+        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        c->fixed_mode = true;
+        return SWR_OK;
+    }
+    c->fixed_mode = false;
+    const uint64_t want = (uint64_t)ntri * 2 + 65536;
+    return ensure_capacity(c, (uint32_t)std::min<uint64_t>(want, 0xFFFFFFF0ull));
+}
 
 DeviceFrame make_frame(swr_context* c, int si, uint64_t frame, const float m[16], uint32_t flags) {
     swr_context::Slot& sl = c->slot[si];
@@ -381,6 +436,11 @@ DeviceFrame make_frame(swr_context* c, int si, uint64_t frame, const float m[16]
     f.live_parity = cull_mode != 0 ? 0 : -1;
     f.bins = (uint32_t*)sl.bins.p;
     f.capacity = c->capacity;
+    f.fixed_bins = (c->fixed_mode && f.ntri > 0) ? 1 : 0;
+    f.cap_tile = c->cap_tile;
+    f.fill = (uint32_t*)c->fillbuf[frame % swr_context::NFILL].p;
+    f.fill_next = (uint32_t*)c->fillbuf[(frame + 1) % swr_context::NFILL].p;
+    f.host_fill = c->h_pairs_dev + swr_context::PAIR_RING + 1 + (frame % swr_context::PAIR_RING);
     f.color = (uint8_t*)c->color[c->fb_cur].p;
     f.depth = (float*)c->depth[c->fb_cur].p;
     f.tg = c->tg;
@@ -419,7 +479,7 @@ int enqueue_frame(swr_context* c) {
     c->hp_begin();
     {
         const BinPlan plan = plan_binning(c->ni / 3, tiles_of(c->tg));
-        if (plan.use_lds) {
+        if (plan.use_lds && !c->fixed_mode) {
             const size_t need = (size_t)plan.G * (size_t)tiles_of(c->tg) * 4;
             bool grow = false;
             for (auto& sl : c->slot) grow = grow || sl.bin_matrix.bytes < need;
@@ -436,6 +496,7 @@ int enqueue_frame(swr_context* c) {
         // an empty band (a group with more sub-contexts than tile rows hands these out): nothing to bin, raster or copy
         int rc = flush_raster(c, c->frame_no);
         if (rc) return rc;
+        fill_word(c, c->frame_no) = 0;
         pair_word(c, c->frame_no++) = 0;
         c->posted = c->frame_no;
         c->bin_enqueued.store(c->frame_no); c->ras_enqueued.store(c->frame_no);
@@ -449,6 +510,7 @@ int enqueue_frame(swr_context* c) {
         const uint64_t frame = c->frame_no++;
         DeviceFrame f = make_frame(c, 0, frame, c->last_m, c->last_flags);
         pair_word(c, frame) = 0;
+        fill_word(c, frame) = 0;
         if ((rc = wait_for_copies_of(c, c->fb_cur, c->stream))) return rc;
         launch_points_or_lines(f, c->last_prim, c->stream);
         HIP_TRY(c, hipGetLastError());
@@ -493,7 +555,17 @@ int enqueue_frame(swr_context* c) {
     if (!sort_sparse && sort_stream_mode < 0 && c->h_pairs[swr_context::PAIR_RING] <= 128u) f.skip_sort = 1;
     const bool all = c->timing >= 2;
     if (f.ntri <= 0) { int rc = sync_streams(c); if (rc) return rc; pair_word(c, frame) = 0; }
-    const bool zero_tables = !f.plan.use_lds || f.ntri <= 0;
+    if (!f.fixed_bins) fill_word(c, frame) = 0;
+    // fixed-stride bins: this frame's fill block must be zero when k_bin starts (the k_bin before it did that, unless that
+    // frame took another path); k_bin leaves it dirty and zeroes the next frame's
+    bool fill_memset = false;
+    if (f.fixed_bins) {
+        const int fbk = (int)(frame % swr_context::NFILL);
+        fill_memset = c->fill_dirty[fbk];
+        c->fill_dirty[fbk] = true;
+        c->fill_dirty[(fbk + 1) % swr_context::NFILL] = false;
+    }
+    const bool zero_tables = !f.fixed_bins && (!f.plan.use_lds || f.ntri <= 0);
     const size_t zero_bytes = (size_t)(CNT_WORDS + 3 * tiles_of(c->tg) + 1) * 4;
     hipEvent_t e0 = (ev && all) ? ev[0] : nullptr, e1 = (ev && all) ? ev[1] : nullptr, e2 = (ev && all) ? ev[2] : nullptr;
     // ---- the binning stream's share of the frame ----
@@ -503,7 +575,7 @@ int enqueue_frame(swr_context* c) {
     // helpers or the caller's own thread?  (idle context: every earlier frame is complete)
     const bool streaming = sb != sr && c->bin_worker && !(c->inline_idle && c->synced_upto == c->posted);
     const bool paced = streaming && c->ras_worker != nullptr;      // cross-stream order by host polls instead of event waits
-    auto bin_share = [c, f, si, sb, sr, frame, zero_tables, zero_bytes, e0, e1, e2, sort_on_raster_stream, slot_wait, paced]() -> int {
+    auto bin_share = [c, f, si, sb, sr, frame, zero_tables, zero_bytes, e0, e1, e2, sort_on_raster_stream, slot_wait, paced, fill_memset]() -> int {
         swr_context::Slot& sl = c->slot[si];
         if (slot_wait) {
             // the first event-carrying raster at or after that frame (RAS_EVERY); its event must have been bound /
@@ -521,14 +593,23 @@ int enqueue_frame(swr_context* c) {
         // global-atomic fallback: counters must start at zero.  Empty scene: no binning kernel runs at all, so the
         // tile table (counts, starts, counters) is simply zeroed.
         if (zero_tables) HIP_TRY(c, hipMemsetAsync(sl.tilebuf.p, 0, zero_bytes, sb));
+        if (fill_memset) HIP_TRY(c, hipMemsetAsync(f.fill, 0, (size_t)(CNT_WORDS + tiles_of(f.tg)) * 4, sb));
         if (e0) HIP_TRY(c, hipEventRecord(e0, sb));
-        launch_setup_bin(f, sb);
-        if (e1) HIP_TRY(c, hipEventRecord(e1, sb));
-        launch_scan(f, sb);
-        if (e2) HIP_TRY(c, hipEventRecord(e2, sb));
         // bin_done = the completion of the chain's last kernel itself (bound at launch) where there is one
         hipEvent_t stop = (sb != sr && c->bind_events) ? sl.bin_done : nullptr;
-        bool bound = launch_fill(f, sb, (sort_on_raster_stream || f.skip_sort) ? stop : nullptr);
+        bool bound;
+        if (f.fixed_bins) {
+            // ONE launch: cull, setup, histogram, region reservation, fill (k_bin)
+            bound = launch_bin(f, sb, (sort_on_raster_stream || f.skip_sort) ? stop : nullptr);
+            if (e1) HIP_TRY(c, hipEventRecord(e1, sb));
+            if (e2) HIP_TRY(c, hipEventRecord(e2, sb));
+        } else {
+            launch_setup_bin(f, sb);
+            if (e1) HIP_TRY(c, hipEventRecord(e1, sb));
+            launch_scan(f, sb);
+            if (e2) HIP_TRY(c, hipEventRecord(e2, sb));
+            bound = launch_fill(f, sb, (sort_on_raster_stream || f.skip_sort) ? stop : nullptr);
+        }
         if (!sort_on_raster_stream && !f.skip_sort) bound = launch_sort_bins(f, sb, stop);
         if (sb != sr && !bound) HIP_TRY(c, hipEventRecord(sl.bin_done, sb));
         HIP_TRY(c, hipGetLastError());
@@ -730,8 +811,13 @@ int single_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vert
     c->ni = index_count;
     c->has_scene = true;
     c->h_pairs[swr_context::PAIR_RING] = 0xFFFFFFFFu;       // fullest bin of the new scene: unknown (sort)
-    const uint64_t want = (uint64_t)(index_count / 3) * 2 + 65536;
-    return ensure_capacity(c, (uint32_t)std::min<uint64_t>(want, 0xFFFFFFF0ull));
+    c->fixed_allowed = true;
+    c->fixed_mode = false;                                  // (re-sized below or at swr_target_set)
+    if (!c->has_target) {
+        const uint64_t want = (uint64_t)(index_count / 3) * 2 + 65536;
+        return ensure_capacity(c, (uint32_t)std::min<uint64_t>(want, 0xFFFFFFF0ull));
+    }
+    return size_bins(c);
 }
 
 int single_scene_attributes(swr_context* c, const swr_vertex_attr* attributes, int64_t vertex_count) {
@@ -815,7 +901,9 @@ int single_target_set(swr_context* c, int64_t width, int64_t height, int64_t row
     c->tg = t;
     c->has_target = true;
     c->h_pairs[swr_context::PAIR_RING] = 0xFFFFFFFFu;       // fullest bin on the new target: unknown (sort)
-    return SWR_OK;
+    c->fixed_allowed = true;
+    c->fixed_mode = false;
+    return size_bins(c);
 }
 
 int check_draw_args(swr_context* c, uint32_t flags, int32_t primitive_type) {
@@ -898,44 +986,64 @@ int check_frames(swr_context* c) {
     auto finish = [&]() -> int {
         harvest(c);
         if (dropped)
-            return fail(c, SWR_ERR_FRAME_DROPPED, "frame %llu of an un-waited burst overflowed the bin capacity (%u pairs) and "
+            return fail(c, SWR_ERR_FRAME_DROPPED, "frame %llu of an un-waited burst overflowed the bin capacity (%u entries) and "
                         "was rastered empty; the bins have been grown — redraw it", (unsigned long long)dropped_frame, dropped_pairs);
         return SWR_OK;
     };
+    // what a frame needed against what the bins give: exact bins count (triangle,tile) pairs, fixed-stride bins the
+    // entries of the fullest tile region
+    auto used = [&](uint64_t f) { return c->fixed_mode ? fill_word(c, f) : pair_word(c, f); };
+    auto limit = [&]() { return c->fixed_mode ? c->cap_tile : c->capacity; };
     for (int attempt = 0; attempt < 8; attempt++) {
         int rc;
         if ((rc = sync_streams(c))) return rc;
         if (!c->draw_pending || c->frame_no == 0) { c->frames_checked = c->frame_no; return finish(); }
         const uint64_t L = c->frame_no - 1;
-        const uint32_t pairs = pair_word(c, L);
+        const uint32_t pairs = used(L);
         uint32_t need = pairs;
+        uint32_t total_pairs = pair_word(c, L);               // (for the switch to exact bins)
         for (uint64_t f = c->frames_checked; f < L; f++) {
-            const uint32_t pf = pair_word(c, f);
-            if (pf > c->capacity) need = std::max(need, pf);
+            const uint32_t pf = used(f);
+            if (pf > limit()) { need = std::max(need, pf); total_pairs = std::max(total_pairs, pair_word(c, f)); }
             // an earlier frame that overflowed was rastered empty: that matters only if it was copied to the host
-            if (pf > c->capacity && c->frame_presented[f % swr_context::PAIR_RING]) {
+            if (pf > limit() && c->frame_presented[f % swr_context::PAIR_RING]) {
                 if (!dropped || pf > dropped_pairs) { dropped_frame = f; dropped_pairs = pf; }
                 dropped = true;
-                need = std::max(need, pf);
             }
         }
         c->frames_checked = L;
-        const uint32_t old_capacity = c->capacity;
-        if (need > old_capacity) {
-            const uint64_t want = (uint64_t)need + need / 4 + 1024;
-            if (want > 0xFFFFFFF0ull) return fail(c, SWR_ERR_UNSUPPORTED, "too many (triangle,tile) pairs: %u", need);
+        const uint32_t old_limit = limit();
+        if (need > old_limit) {
             if ((rc = sync_copies(c))) return rc;
-            if ((rc = ensure_capacity(c, (uint32_t)want))) return rc;
+            if (c->fixed_mode) {
+                const uint32_t cmax = fixed_cap_max(c->ni / 3, tiles_of(c->tg));
+                if (need > cmax) {
+                    // a tile needs more than a fixed region can hold: exact-size bins (four binning kernels) from here on
+                    c->fixed_mode = false;
+                    c->fixed_allowed = false;
+                    const uint64_t want = (uint64_t)total_pairs + total_pairs / 4 + 1024;
+                    if (want > 0xFFFFFFF0ull) return fail(c, SWR_ERR_UNSUPPORTED, "too many (triangle,tile) pairs: %u", total_pairs);
+                    if ((rc = ensure_capacity(c, (uint32_t)want))) return rc;
+                } else {
+                    const uint64_t want = std::min<uint64_t>(cmax, (((uint64_t)need + need / 4 + 64) + 63) & ~63ull);
+                    if ((rc = ensure_bins(c, (size_t)tiles_of(c->tg) * (size_t)want))) return rc;
+                    c->cap_tile = (uint32_t)want;
+                }
+            } else {
+                const uint64_t want = (uint64_t)need + need / 4 + 1024;
+                if (want > 0xFFFFFFF0ull) return fail(c, SWR_ERR_UNSUPPORTED, "too many (triangle,tile) pairs: %u", need);
+                if ((rc = ensure_capacity(c, (uint32_t)want))) return rc;
+            }
         }
-        if (pairs <= old_capacity) {
+        if (pairs <= old_limit) {
             c->draw_pending = false;
             c->frames_checked = c->frame_no;
-            c->last.tile_pairs = pairs;
+            c->last.tile_pairs = pair_word(c, L);
             c->last.tiles = tiles_of(c->tg);
             c->last.triangles = c->ni / 3;
             return finish();
         }
-        // the last frame's (triangle,tile) pair list overflowed: redraw it into the same framebuffer, copy it again
+        // the last frame overflowed: redraw it into the same framebuffer, copy it again
         c->fb_cur = c->fb_last;
         if ((rc = enqueue_frame(c))) return rc;
         if (c->present_pending && (rc = enqueue_present(c, c->present_color, c->present_depth))) return rc;
@@ -982,7 +1090,8 @@ void destroy_single(swr_context* c) {
                 (unsigned long long)c->hp_frames, c->hp_t[0] / c->hp_frames, c->hp_t[1] / c->hp_frames, c->hp_t[2] / c->hp_frames,
                 c->hp_t[3] / c->hp_frames, c->hp_t[4] / c->hp_frames, c->hp_t[5] / c->hp_frames);
     DevBuf* bufs[] = {&c->vertices, &c->indices, &c->tri_rgb, &c->tri_xyz, &c->inv, &c->box64, &c->stream_scratch, &c->sort_temp,
-                      &c->attrs, &c->tri_nrm, &c->texture, &c->texture_bytes, &c->color[0], &c->color[1], &c->depth[0], &c->depth[1]};
+                      &c->attrs, &c->tri_nrm, &c->texture, &c->texture_bytes, &c->color[0], &c->color[1], &c->depth[0], &c->depth[1],
+                      &c->fillbuf[0], &c->fillbuf[1], &c->fillbuf[2], &c->fillbuf[3]};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& sl : c->slot) {
         DevBuf* sb[] = {&sl.geo, &sl.geo_full, &sl.ranges, &sl.bins, &sl.bin_matrix, &sl.live, &sl.tilebuf};
@@ -1018,14 +1127,14 @@ int create_single(int dev, swr_context** out) {
         (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->copy_stream[0], hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->copy_stream[1], hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipHostMalloc((void**)&c->h_pairs, (swr_context::PAIR_RING + 1) * 4, hipHostMallocMapped)) != hipSuccess ||
+        (e = hipHostMalloc((void**)&c->h_pairs, (2 * swr_context::PAIR_RING + 1) * 4, hipHostMallocMapped)) != hipSuccess ||
         (e = hipHostGetDevicePointer((void**)&c->h_pairs_dev, c->h_pairs, 0)) != hipSuccess ||
         (e = hipHostMalloc((void**)&c->h_misc, CNT_WORDS * 4, hipHostMallocDefault)) != hipSuccess) {
         int rc = fail(nullptr, SWR_ERR_HIP, "context init on device %d failed: %s", dev, hipGetErrorString(e));
         destroy_single(c);
         return rc;
     }
-    memset(c->h_pairs, 0, (swr_context::PAIR_RING + 1) * 4);
+    memset(c->h_pairs, 0, (2 * swr_context::PAIR_RING + 1) * 4);
     c->h_pairs[swr_context::PAIR_RING] = 0xFFFFFFFFu;     // fullest bin: unknown
     memset(c->h_misc, 0, CNT_WORDS * 4);
     {

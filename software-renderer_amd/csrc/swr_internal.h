@@ -90,7 +90,13 @@ struct DeviceFrame {
     int32_t skip_sort;             // 1: no k_sort_bins for this frame (every bin of the previous frames fitted two chunks)
     uint32_t* tile_cursor;         // [tiles] running fill position (starts as tile_start)
     uint2* ranges;                 // [ntri] band-clipped pixel bbox (x0|x1<<16, y0|y1<<16, y band-relative)
-    uint32_t* bins;                // [capacity] primitive ids grouped by tile
+    uint32_t* bins;                // [capacity] primitive ids grouped by tile (exact bins) / [tiles * cap_tile] (fixed-stride bins)
+    // fixed-stride bins (k_bin, one launch): tile t owns bins[t * cap_tile, +fill[CNT_WORDS + t])
+    int32_t fixed_bins;            // 1: this frame is binned by k_bin
+    uint32_t cap_tile;             // entries per tile region
+    uint32_t* fill;                // [CNT_WORDS counters][tiles] of this frame, zero when k_bin starts
+    uint32_t* fill_next;           // the next frame's block (k_bin zeroes it)
+    uint32_t* host_fill;           // pinned host word: the frame's largest fill (overflow test)
     uint32_t* bin_matrix;          // [G][tiles] per-workgroup tile counts -> prefixes (LDS path)
     uint32_t* live;                // [G][1 + ceil(groups/G)] per binning workgroup: count + the stream groups that survived its cull
     int32_t live_parity;           // >= 0: cull the groups against the band; -1: every group is live
@@ -121,6 +127,8 @@ hipError_t launch_build_stream(const StreamBuild& b, hipStream_t s);
 void launch_gather_attrs(const swr_vertex_attr* attrs, int64_t nv, const int64_t* indices, int64_t ntri,
                          const float4* tri_xyz, float4* tri_nrm, float4* tri_rgb, hipStream_t s);
 void launch_texture_to_float(const uint32_t* bgra, int64_t n, float4* out, hipStream_t s);
+uint32_t fixed_cap_max(int64_t ntri, int ntiles);   // largest tile region k_bin can fill (0: the frame needs the exact-size path)
+bool launch_bin(const DeviceFrame& f, hipStream_t s, hipEvent_t stop = nullptr);
 void launch_setup_bin(const DeviceFrame& f, hipStream_t s);
 void launch_scan(const DeviceFrame& f, hipStream_t s);
 // stop != NULL: the event is bound to the (last) kernel launched, as its completion; returns whether a kernel carries it

@@ -694,6 +694,172 @@ __global__ __launch_bounds__(BT) void k_fill_lds(const uint2* __restrict__ range
     }
 }
 
+// ---- binning in ONE kernel, fixed-stride bins (default) --------------------------------------------------------
+// The bin of tile t is the fixed region bins[t * cap, (t + 1) * cap): there is no prefix over tiles, so nothing in the
+// frame depends on the totals of ALL binning workgroups and the whole chain k_setup_hist -> k_colscan -> k_fill_lds
+// collapses into one launch:
+//   1  cull: one lane per owned 64-primitive group (as k_setup_hist)
+//   2  per triangle: 3 x vertex_shader, /w, screen map, truncation, y-sort -> GeomRec, ranges; the workgroup's tile
+//      histogram in LDS, two 16-bit counters per word
+//   3  one RETURNING global atomic per (workgroup, tile it touches) reserves the workgroup's run inside the tile's
+//      region: base = atomicAdd(fill[t], count).  The stream is Morton-ordered and a workgroup owns every G-th group,
+//      so it touches a few hundred tiles, not all of them (cfg4: ~220 K atomics per frame, 16 or more in flight per
+//      lane).  The LDS word now holds the two 16-bit cursors.
+//   4  second walk over the same groups (ranges are L2-hot): bins[t * cap + ds_add_rtn(cursor[t])] = slot | class.
+// fill[] must be zero on entry: the kernel zeroes the NEXT frame's array (four arrays rotate while the working sets
+// rotate by three, so the array zeroed here was last read by a raster that finished before this kernel could start).
+// A tile that receives more than cap entries overflows: the frame's largest fill goes to the host, which grows cap and
+// redraws (or falls back to the exact-size path above when a tile needs more than FIXED_CAP_MAX entries).
+struct BinArgs {
+    SetupArgs a;
+    uint32_t* fill;         // [CNT_WORDS counters][ntiles] of this frame (zero on entry)
+    uint32_t* fill_next;    // the same block of the next frame: zeroed here
+    uint32_t* bins;         // [ntiles * cap]
+    uint32_t cap;           // entries per tile, <= FIXED_CAP_MAX
+    int per;                // stream groups owned by one workgroup
+    int ntiles;
+    int tag_class;
+};
+constexpr uint32_t FIXED_CAP_MAX = 61440u;   // cursor halves stay below 2^16: cap + primitives owned by one workgroup < 65536
+enum { CNT_MAXFILL = 3 };
+
+template <int BT>
+__global__ __launch_bounds__(BT) void k_bin(BinArgs b) {
+    extern __shared__ uint32_t hist[];               // [(ntiles + 1) / 2] counters -> cursors, [per] surviving groups, [1] their count, [2 * BT / 64] reduction
+    const SetupArgs& a = b.a;
+    const int ntiles = b.ntiles, per = b.per;
+    const int hwords = (ntiles + 1) >> 1;
+    uint32_t* mylist = hist + hwords;
+    uint32_t& nlive_s = mylist[per];
+    uint32_t* red = mylist + per + 1;
+    const int t = threadIdx.x, lane = t & 63;
+    if (t == 0) nlive_s = 0u;
+    for (int e = t; e < hwords; e += BT) hist[e] = 0u;
+    {   // the next frame's counters and fill words
+        uint32_t* fn = b.fill_next;
+        for (int e = blockIdx.x * BT + t; e < CNT_WORDS + ntiles; e += gridDim.x * BT) fn[e] = 0u;
+    }
+    __syncthreads();
+    {
+        const int64_t groups = (a.ntri + 63) >> 6;
+        for (int i0 = t & ~63; i0 < per; i0 += BT) {                 // wave-uniform trip count
+            const int i = i0 + lane;
+            const int64_t g = (int64_t)i * gridDim.x + blockIdx.x;
+            const bool keep = i < per && g < groups && !(a.cull && group_culled(a, g));
+            const unsigned long long mask = __ballot(keep);
+            uint32_t base = 0u;
+            if (lane == 0 && mask) base = atomicAdd(&nlive_s, (uint32_t)__popcll(mask));
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (keep) mylist[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = (uint32_t)g;
+        }
+    }
+    __syncthreads();
+    const uint32_t nlive = nlive_s;
+    const int tiles_x = a.tg.tiles_x;
+    // ---- 2: setup + histogram (the 48 B per lane of the NEXT group in flight while this one is transformed)
+    {
+        float4 nxa = make_float4(0, 0, 0, 0), nxb = nxa, nxc = nxa;
+        {
+            const uint32_t j0 = t >> 6;
+            const int64_t p0 = j0 < nlive ? ((int64_t)mylist[j0] << 6) + lane : a.ntri;
+            if (p0 < a.ntri) { nxa = a.tri_xyz[3 * p0 + 0]; nxb = a.tri_xyz[3 * p0 + 1]; nxc = a.tri_xyz[3 * p0 + 2]; }
+        }
+        for (uint32_t j = t >> 6; j < nlive; j += BT / 64) {
+            const int64_t p = ((int64_t)mylist[j] << 6) + lane;
+            const float4 xa = nxa, xb = nxb, xc = nxc;
+            {
+                const uint32_t jn = j + BT / 64;
+                const int64_t pn = jn < nlive ? ((int64_t)mylist[jn] << 6) + lane : a.ntri;
+                if (pn < a.ntri) { nxa = a.tri_xyz[3 * pn + 0]; nxb = a.tri_xyz[3 * pn + 1]; nxc = a.tri_xyz[3 * pn + 2]; }
+            }
+            uint2 r = make_uint2(RANGE_NONE_X, 0u);
+            if (p < a.ntri) {
+                r = setup_triangle(a, p, xa, xb, xc);
+                a.ranges[p] = r;
+            }
+            for_each_tile(unpack_box(r), (uint32_t)p, [&](const PixBox&, uint32_t, int tx, int ty) {
+                const int tile = ty * tiles_x + tx;
+                atomicAdd(&hist[tile >> 1], 1u << ((tile & 1) << 4));
+            });
+        }
+    }
+    __syncthreads();
+    // ---- 3: reserve this workgroup's run in every tile region it touches
+    uint32_t psum = 0u, pmax = 0u;
+    {
+        uint32_t* fill = b.fill + CNT_WORDS;
+        constexpr int U = 4;
+        for (int w0 = t; w0 < hwords; w0 += BT * U) {
+            uint32_t cw[U], b0[U], b1[U];
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const int w = w0 + k * BT;
+                cw[k] = w < hwords ? hist[w] : 0u;
+                b0[k] = b1[k] = 0u;
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++) {             // up to 2 U independent returning atomics in flight per lane
+                const int w = w0 + k * BT;
+                const uint32_t c0 = cw[k] & 0xFFFFu, c1 = cw[k] >> 16;
+                if (c0) b0[k] = atomicAdd(&fill[2 * w], c0);
+                if (c1) b1[k] = atomicAdd(&fill[2 * w + 1], c1);
+            }
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const int w = w0 + k * BT;
+                const uint32_t c0 = cw[k] & 0xFFFFu, c1 = cw[k] >> 16;
+                psum += c0 + c1;
+                if (c0) pmax = max(pmax, b0[k] + c0);
+                if (c1) pmax = max(pmax, b1[k] + c1);
+                if (w < hwords) hist[w] = min(b0[k], b.cap) | (min(b1[k], b.cap) << 16);
+            }
+        }
+    }
+    {
+        // totals of the frame: workgroup sums -> two device counters; the last workgroup to arrive hands them to the host
+        const uint32_t ws = (uint32_t)wave_incl_add((int)psum);
+        uint32_t wm = pmax;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) wm = max(wm, (uint32_t)__shfl_xor((int)wm, off));
+        if (lane == 63) red[t >> 6] = ws;
+        if (lane == 0) red[BT / 64 + (t >> 6)] = wm;
+    }
+    __syncthreads();     // also orders the cursor words written above before the second walk
+    if (t == 0) {
+        // fire and forget: k_raster of this frame (which starts when this kernel has finished) hands the two totals to
+        // the host.  (A ticket + last-workgroup-publishes protocol was built first: five dependent round trips to memory
+        // in one lane put 8 us on the tail of the kernel: a thin band's k_bin 27 us against 20.)
+        uint32_t s = 0u, m = 0u;
+        for (int k = 0; k < BT / 64; k++) { s += red[k]; m = max(m, red[BT / 64 + k]); }
+        uint32_t* cnt = b.fill;
+        if (s) atomicAdd(&cnt[CNT_PAIRS], s);
+        if (m) atomicMax(&cnt[CNT_MAXFILL], m);
+    }
+    // ---- 4: second walk, same groups, same order
+    constexpr int FB = 4;
+    for (uint32_t j0 = t >> 6; j0 < nlive; j0 += FB * (BT / 64)) {
+        int64_t pp[FB];
+        uint2 rr[FB];
+#pragma unroll
+        for (int k = 0; k < FB; k++) {
+            const uint32_t j = j0 + (uint32_t)k * (BT / 64);
+            pp[k] = j < nlive ? ((int64_t)mylist[j] << 6) + lane : a.ntri;
+            rr[k] = pp[k] < a.ntri ? a.ranges[pp[k]] : make_uint2(RANGE_NONE_X, 0u);
+        }
+#pragma unroll
+        for (int k = 0; k < FB; k++) {
+            if (j0 + (uint32_t)k * (BT / 64) >= nlive) break;            // wave-uniform
+            for_each_tile(unpack_box(rr[k]), (uint32_t)pp[k], [&](const PixBox& bx, uint32_t prim, int tx, int ty) {
+                const int tile = ty * tiles_x + tx;
+                const uint32_t sh = (uint32_t)(tile & 1) << 4;
+                const uint32_t pos = (atomicAdd(&hist[tile >> 1], 1u << sh) >> sh) & 0xFFFFu;
+                if (pos < b.cap)
+                    b.bins[(size_t)tile * b.cap + pos] = prim | (b.tag_class ? size_class(bx, tx, ty) << CLASS_SHIFT : 0u);
+            });
+        }
+    }
+}
+
 // ---- binning, global-atomic path (fallback when the tile table does not fit LDS) --------------
 __global__ __launch_bounds__(256) void k_setup_bin(SetupArgs a) {
     const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -773,11 +939,18 @@ constexpr int SORT_CAP = 4 * SORT_THREADS;
 __global__ __launch_bounds__(SORT_THREADS) void k_sort_bins(uint32_t* __restrict__ bins,
                                                             const uint32_t* __restrict__ tile_start,
                                                             const uint32_t* __restrict__ counters,
-                                                            uint32_t capacity, int tag_class) {
+                                                            uint32_t capacity, int tag_class,
+                                                            const uint32_t* __restrict__ fill, uint32_t fixed_cap) {
     __shared__ uint32_t cls_cnt[64];
-    if (counters[CNT_PAIRS] > capacity) return;
     const int tid = threadIdx.x;
-    const uint32_t b0 = tile_start[blockIdx.x], b1 = tile_start[blockIdx.x + 1];
+    uint32_t b0, b1;
+    if (fixed_cap) {        // fixed-stride bins (k_bin): tile t owns [t * cap, t * cap + fill[t])
+        b0 = blockIdx.x * fixed_cap;
+        b1 = b0 + min(fill[CNT_WORDS + blockIdx.x], fixed_cap);
+    } else {
+        if (counters[CNT_PAIRS] > capacity) return;
+        b0 = tile_start[blockIdx.x]; b1 = tile_start[blockIdx.x + 1];
+    }
     for (uint32_t seg = b0; seg < b1; seg += SORT_CAP) {
         const uint32_t m = min((uint32_t)SORT_CAP, b1 - seg);
         if (tid < 64) cls_cnt[tid] = 0u;
@@ -831,6 +1004,11 @@ struct RasterArgs {
     float* depth;       // band-local f32
     Target tg;
     int tag_class;      // bin entries carry a size class above bit CLASS_SHIFT
+    const uint32_t* fill;   // fixed-stride bins (k_bin): [CNT_WORDS counters][ntiles fills]; NULL = exact bins (tile_start)
+    uint32_t fixed_cap;     // entries per tile region (0 = exact bins)
+    uint32_t* host_pairs;   // fixed-stride bins: pinned host words for the frame's pair total, its largest fill (the overflow
+    uint32_t* host_fill;    // test) and the same for the host's sort heuristic — k_bin leaves them in device counters
+    uint32_t* host_max;
     int vs_log;         // 2^vs_log workgroups per tile, each owning TILE_H >> vs_log of its rows (small grids, see launch_raster)
 };
 
@@ -898,6 +1076,19 @@ __device__ __forceinline__ void load_tri(const GeomFull* __restrict__ full, uint
     maxx = max(vx[0], max(vx[1], vx[2]));
 }
 
+// Lane mask of a <= b as a scalar (v_cmp writes 0 for lanes outside EXEC).
+#ifndef SWR_ASM_MASKS
+#define SWR_ASM_MASKS 1
+#endif
+__device__ __forceinline__ unsigned long long lane_mask_le(int a, int b) {
+#if SWR_ASM_MASKS
+    unsigned long long m;
+    asm("v_cmp_le_i32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+#else
+    return __builtin_amdgcn_ballot_w64(a <= b);
+#endif
+}
 __device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ float bcast_f(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
@@ -1004,9 +1195,19 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
     const int Yp1 = min(Yp0 + PROWS - 1, Y1);
     if (Yp0 > Y1) return;     // the band ends above this slice (workgroup-uniform)
 
-    const bool overflow = a.counters[CNT_PAIRS] > a.capacity;
-    const uint32_t b0 = overflow ? 0u : a.tile_start[tile];
-    const uint32_t b1 = overflow ? 0u : a.tile_start[tile + 1];
+    // an overflowed frame (more pairs than the bins hold / a tile region too small) is rastered empty: the host grows the
+    // bins and redraws it
+    uint32_t b0 = 0u, b1 = 0u;
+    if (a.fixed_cap && blockIdx.x == 0 && threadIdx.x == 0) {
+        *a.host_pairs = a.fill[CNT_PAIRS];
+        *a.host_fill = a.fill[CNT_MAXFILL];
+        if (a.host_max) *a.host_max = a.fill[CNT_MAXFILL];
+    }
+    if (a.fixed_cap) {
+        if (a.fill[CNT_MAXFILL] <= a.fixed_cap) { b0 = (uint32_t)tile * a.fixed_cap; b1 = b0 + a.fill[CNT_WORDS + tile]; }
+    } else if (a.counters[CNT_PAIRS] <= a.capacity) {
+        b0 = a.tile_start[tile]; b1 = a.tile_start[tile + 1];
+    }
     const uint32_t m = b1 - b0;   // bin sorted by size class (k_sort_bins), heaviest first — unless the host skipped the sort
     // (sparse frames, launch_sort_bins): the entries then still carry k_fill_lds's class tag
     const uint32_t bin_mask = a.tag_class ? (1u << CLASS_SHIFT) - 1u : 0xFFFFFFFFu;
@@ -1078,14 +1279,11 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
         bool big = false, large = false;
         if (have) {
             int minx, maxx;
-            uint32_t prim = prim_pre;
-            int4 q0 = q0_pre;
-            float4 q1 = q1_pre;
-            if (!first_chunk) {
-                prim = a.bins[b0 + e] & bin_mask;
-                q0 = reinterpret_cast<const int4*>(a.geo + prim)[0];
-                q1 = reinterpret_cast<const float4*>(a.geo + prim)[1];
-            }
+            // bin entry and record of this chunk were fetched ahead: the first chunk's before the LDS init, a later
+            // one's while the previous chunk was being finished (steal_next below)
+            const uint32_t prim = prim_pre;
+            const int4 q0 = q0_pre;
+            const float4 q1 = q1_pre;
             if (METAL) {
                 // TriState re-used: t00..t11 = A0,B0,A1,B1 of the `divider` formula, cf.y = p3.y, cx = p3.x,
                 // ch.s0 / ch.s2 = ROI min / max corner
@@ -1250,6 +1448,28 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
         // screen-filling triangles): the same machinery with UPX = 32 pixels per visit (SL = 3) instead of 4 — the
         // consumer walks its share in eight groups of four and a 64-pixel row is two visits.  The two instantiations
         // are chosen per chunk (wave-uniform).
+        // The next chunk of this wave (the following one when the waves split rows, else stolen from the counter) is
+        // chosen as soon as the rows of this one have run out, and its bin entries are fetched while the ring is
+        // drained — the gather chain bin entry -> record of a chunk is two dependent round trips to memory.  (Stealing
+        // at the START of a chunk was measured in round 2 and lost: a chunk reserved by a wave that is still busy with a
+        // heavy one is a chunk no idle wave can take.  Here the wave has at most a few consumer steps left.)
+#ifndef SWR_STEAL_AHEAD
+#define SWR_STEAL_AHEAD 0   // measured: choosing the next chunk when the rows run out (2-3 consumer steps early) costs k_raster 70.7 -> 73.7 us, profiles/r03/steal_ahead_ab.txt
+#endif
+        uint32_t chunk_next = nchunks;
+        bool have_next = false;
+        auto steal_next = [&]() {
+            if (rowsplit) {
+                chunk_next = chunk + 1u;
+            } else {
+                uint32_t nx = 0u;
+                if (lane == 0) nx = atomicAdd(&next_chunk, 1u);
+                chunk_next = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
+            }
+            const uint32_t e2 = chunk_next * csz + (uint32_t)lane;
+            have_next = chunk_next < nchunks && (uint32_t)lane < csz && e2 < m;
+            if (have_next) prim_pre = a.bins[b0 + e2] & bin_mask;
+        };
         auto dense = [&](auto SLc) {
             constexpr int SL = decltype(SLc)::value;            // log2 of the 4-pixel groups per visit
             constexpr int UPX = UNIT << SL;                     // pixels of a span one lane handles per visit
@@ -1266,10 +1486,11 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             int y = mine ? ya : 1;
             const int ye = mine ? yb : 0;
             uint32_t qhead = 0u, qcount = 0u;   // wave-uniform
+            bool stolen = false;                // the next chunk has been chosen (wave-uniform)
             uint32_t* const q = queue[tid >> 6];
             // ring entry = owner lane | xl << 6 | yl << 12 | (pixels - 1) << 17, xl / yl tile-local
             static_assert(TILE_W == 64 && TILE_H == 32 && UNIT == 4, "ring entry layout: 6 + 6 + 5 + 6 bits");
-            uint32_t ebase = (uint32_t)lane | ((uint32_t)((y - Y0) & (TILE_H - 1)) << 12);
+            uint32_t ebase = ((uint32_t)lane | ((uint32_t)((y - Y0) & (TILE_H - 1)) << 12)) - ((uint32_t)X0 << 6);
             // The two chains of draw(triangle:) (:276-277) as row steppers.  Left chain [S0,S1,S2]: the segment the
             // first row of the tile falls into, switched to [S1,S2] at the row y == S1.y (:469-475); right chain [S0,S2].
             // At y == S2.y the interpolant returns S2.x (:469-471): the stepper of [S1,S2] arrives there by itself
@@ -1387,15 +1608,17 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                 }   // sg
                 // the rest of a span longer than this visit goes back into the ring (behind everything that waits)
                 const bool more = (!TAIL || (lane >> sh) == 0) && (!TAIL || idx < n) && len > visit;
-                const unsigned long long mb = __ballot(more);
+                const unsigned long long mb = __builtin_amdgcn_ballot_w64(more);
                 if (more)
                     q[(qhead + qcount + rank_of(mb)) & (uint32_t)(QCAP - 1)] = e + ((uint32_t)visit << 6) - ((uint32_t)visit << 17);
                 qhead += n;
                 qcount = qcount - n + (uint32_t)__popcll(mb);
             };
             for (;;) {
-                while (VAR != 4 && VAR != 10 && qcount < 64u && __any(y <= ye)) {
-                    const bool act = y <= ye;
+                // (lane masks straight from v_cmp: hipcc turns a ballot inside this loop into v_cndmask + v_cmp_ne on top
+                // of the compare; control flow is wave-uniform here, EXEC is all ones)
+                unsigned long long am = lane_mask_le(y, ye);                 // lanes with rows left
+                while (VAR != 4 && VAR != 10 && qcount < 64u && am != 0ull) {
                     int lo, hi;
                     if (METAL) {
                         lo = max(t.ch.s0x, X0); hi = min(t.ch.s2x, X1);      // every ROI row spans the ROI's x-range
@@ -1403,12 +1626,12 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                         lo = max(min(eL.X, eR.X), X0);                       // :278-280 swap, then the tile's scissor
                         hi = min(max(eL.X, eR.X), X1);
                     }
-                    const bool put = act && lo <= hi;
-                    const unsigned long long pb = __ballot(put);
-                    if (put)
+                    // two single-compare ballots and a scalar AND: a ballot of (a && b) costs two more vector instructions
+                    const unsigned long long pb = am & lane_mask_le(lo, hi);     // lanes with a non-empty span in this row
+                    if (__builtin_amdgcn_inverse_ballot_w64(pb))
                         q[(qhead + qcount + rank_of(pb)) & (uint32_t)(QCAP - 1)] =
-                            ebase + ((uint32_t)(lo - X0) << 6) + ((uint32_t)(hi - lo) << 17);
-                    if (act) {
+                            ((uint32_t)(hi - lo) << 17) + (((uint32_t)lo << 6) + ebase);    // ebase holds -X0 << 6
+                    if (__builtin_amdgcn_inverse_ballot_w64(am)) {
                         y += 1;
                         ebase += 1u << 12;
                         if (!METAL) {
@@ -1418,7 +1641,9 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                         }
                     }
                     qcount += (uint32_t)__popcll(pb);
+                    am = lane_mask_le(y, ye);
                 }
+                if (SWR_STEAL_AHEAD && !stolen && am == 0ull) { stolen = true; steal_next(); }
                 if (qcount == 0u) break;
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
                 if (VAR == 3) { const uint32_t n = min(qcount, 64u); qhead += n; qcount -= n; continue; }
@@ -1426,6 +1651,7 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                 else consume(std::true_type{});
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
             }
+            if (!stolen) steal_next();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next chunk rewrites the tables
         };
         {
@@ -1435,14 +1661,12 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             if (dm != 0ull && 2 * __popcll(lg) >= __popcll(dm)) dense(std::integral_constant<int, 3>{});
             else dense(std::integral_constant<int, 0>{});
         }
-        // the next chunk (wave-uniform): the following one when the waves split rows, else stolen from the counter
+        // the next chunk (wave-uniform, chosen by steal_next): its records, now that the bin entries have arrived
         first_chunk = false;
-        if (rowsplit) {
-            chunk += 1u;
-        } else {
-            uint32_t nx = 0u;
-            if (lane == 0) nx = atomicAdd(&next_chunk, 1u);
-            chunk = (uint32_t)__builtin_amdgcn_readfirstlane((int)nx);
+        chunk = chunk_next;
+        if (have_next) {
+            q0_pre = reinterpret_cast<const int4*>(a.geo + prim_pre)[0];
+            q1_pre = reinterpret_cast<const float4*>(a.geo + prim_pre)[1];
         }
     }
     __syncthreads();
@@ -1738,6 +1962,7 @@ hipError_t prepare_device() {
     if ((e = hipFuncSetAttribute((const void*)k_fill_lds<BIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_bin<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)k_fill_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -1781,6 +2006,33 @@ void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
     }
 }
 
+// Can the frame be binned by the single-launch k_bin (fixed-stride bins), and how large may a tile region be?  Needs the
+// LDS path's 16-bit histogram, class tags, 32-bit offsets into the region table, and cursor halves that stay below 2^16:
+// region size + the primitives one workgroup owns < 65536.
+uint32_t fixed_cap_max(int64_t ntri, int ntiles) {
+    if (ntri <= 0 || ntiles <= 0 || ntri >= (1ll << CLASS_SHIFT)) return 0u;
+    const BinPlan p = plan_binning(ntri, ntiles);
+    if (!p.use_lds || p.threads != 256) return 0u;
+    const int64_t own = (int64_t)live_groups_per_workgroup(ntri, p.G) * 64;
+    if (own >= 65535 - 1024) return 0u;
+    if ((size_t)((ntiles + 1) / 2) * 4 + (size_t)(own / 64 + 1) * 4 + 64 > 150 * 1024) return 0u;
+    const uint64_t by_offset = 0xFFFFFFFFull / (uint64_t)ntiles;
+    const uint64_t by_cursor = (uint64_t)(65535 - own);
+    return (uint32_t)std::min<uint64_t>(std::min<uint64_t>(FIXED_CAP_MAX, by_offset), by_cursor) & ~63u;
+}
+
+bool launch_bin(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
+    BinArgs b;
+    b.a = make_setup_args(f);
+    b.fill = f.fill; b.fill_next = f.fill_next; b.bins = f.bins; b.cap = f.cap_tile;
+    b.ntiles = f.tg.tiles_x * f.tg.tiles_y;
+    b.per = live_groups_per_workgroup(f.ntri, f.plan.G);
+    b.tag_class = f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0;
+    const size_t lds = (size_t)((b.ntiles + 1) / 2) * 4 + (size_t)(b.per + 1) * 4 + 2 * (256 / 64) * 4;
+    SWR_LAUNCH(stop, k_bin<256>, dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b);
+    return stop != nullptr;
+}
+
 void launch_scan(const DeviceFrame& f, hipStream_t s) {
     if (f.plan.use_lds && f.ntri > 0) return;   // LDS path: the scan is fused into k_fill_lds
     const int n = f.tg.tiles_x * f.tg.tiles_y;
@@ -1815,7 +2067,8 @@ bool launch_sort_bins(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     const unsigned tiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
     if (f.ntri <= 0 || tiles == 0 || f.skip_sort) return false;
     SWR_LAUNCH(stop, k_sort_bins, dim3(tiles), dim3(SORT_THREADS), 0, s, f.bins, (const uint32_t*)f.tile_start,
-               (const uint32_t*)f.counters, f.capacity, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0);
+               (const uint32_t*)f.counters, f.capacity, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0,
+               (const uint32_t*)(f.fixed_bins ? f.fill : nullptr), f.fixed_bins ? f.cap_tile : 0u);
     return stop != nullptr;
 }
 
@@ -1834,6 +2087,9 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     a.color = (f.flags & SWR_FLAG_NO_COLOR) ? nullptr : f.color;
     a.depth = f.depth; a.tg = f.tg;
     a.tag_class = f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0;
+    a.fill = f.fixed_bins ? f.fill : nullptr;
+    a.fixed_cap = f.fixed_bins ? f.cap_tile : 0u;
+    a.host_pairs = f.host_counters; a.host_fill = f.host_fill; a.host_max = f.host_max;
     const unsigned ntiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
     if (ntiles == 0) return false;
     // Small grids (a small window: the reference app's 512x512 is 128 tiles): four workgroups fit where one tile's

@@ -338,6 +338,51 @@ def test_global_atomic_binning_fallback(swr, oracle, monkeypatch):
             check(ctx, oracle, s)
 
 
+def test_exact_size_bins_path(swr, oracle, monkeypatch):
+    """The four-kernel binning with exact-size bins (k_setup_hist / k_colscan / k_fill_lds / k_sort_bins): the fallback
+    of the single-launch k_bin (fixed-stride bins), forced via SWR_BIN_MODE."""
+    monkeypatch.setenv("SWR_BIN_MODE", "exact")
+    for flags in (0, DT, 4):
+        s = swr.scenes.random_soup(30000, 1280, 720, 321, r_ndc=0.03, flags=flags & 3, margin=1.1)
+        with swr.Context() as ctx:
+            if flags == 4:                      # SWR_FLAG_METAL_RULES
+                check_metal(ctx, oracle, s)
+            else:
+                check(ctx, oracle, s)
+            assert ctx.timings()["tile_pairs"] > 30000
+
+
+def crowded_tile_scene(swr, ntri, flags=DT):
+    """ntri small triangles that all fall into one 64x32 tile of a 1280x720 frame (plus a thin soup elsewhere)."""
+    s = swr.scenes.random_soup(ntri, 1280, 720, 555, r_ndc=0.01, flags=flags, margin=1.0)
+    v = s.vertices.copy()
+    # squeeze every vertex into NDC [0.30, 0.37] x [0.10, 0.16]: inside the tile (13, 9) of the 20 x 23 tile grid
+    v[:, 0] = 0.30 + (v[:, 0] * 0.5 + 0.5) * 0.07
+    v[:, 1] = 0.10 + (v[:, 1] * 0.5 + 0.5) * 0.06
+    s.vertices = np.ascontiguousarray(v)
+    return s
+
+
+def test_fixed_stride_bins_regrow_and_fall_back(swr, oracle):
+    """k_bin's tile regions: a tile that receives more entries than its region holds makes the host grow the regions
+    and redraw (20 000 triangles in one tile against the initial 4 096); a tile that needs more than a region can ever
+    hold (cursor halves are 16 bits) switches the context to exact-size bins."""
+    for ntri in (20000, 140000):
+        s = crowded_tile_scene(swr, ntri)
+        rc, rd, st, code = oracle.render_scene(s, oracle.TINV_PER_TRIANGLE)
+        assert code == 0 and st.fragments >= ntri
+        with swr.Context() as ctx:
+            c, d = ctx.render(s.vertices, s.indices, s.transform, s.width, s.height, s.flags)
+            assert_same(c, d, rc, rd, f"crowded tile, {ntri} triangles")
+            # resident frames after the repair: a burst, presented, must not report a drop any more
+            ctx.scene_upload(s.vertices, s.indices)
+            ctx.target_set(s.width, s.height)
+            for _ in range(3):
+                ctx.draw(s.transform, s.flags)
+            ctx.sync()
+            assert_same(ctx.read_color(), ctx.read_depth(), rc, rd, f"crowded tile, resident, {ntri}")
+
+
 def test_host_mirror_cpp_program(swr):
     """The C++ mirror of the reference's host interface, driven like App.swift:153-185."""
     import os

@@ -170,8 +170,26 @@ def big_scene(swr, ntri=220):
     return swr.scenes.random_soup(ntri, 3840, 2160, 77, r_ndc=1.4, flags=DT, margin=0.3)
 
 
-def test_bin_overflow_is_repaired_or_reported(swr, oracle):
-    s = big_scene(swr)
+def crowded_scene(swr, ntri=20000):
+    """ntri small triangles inside two neighbouring tiles of a 1280x720 frame: far more entries than the initial tile
+    region of the fixed-stride bins (k_bin) holds."""
+    s = swr.scenes.random_soup(ntri, 1280, 720, 555, r_ndc=0.01, flags=DT, margin=1.0)
+    v = s.vertices.copy()
+    v[:, 0] = 0.30 + (v[:, 0] * 0.5 + 0.5) * 0.07
+    v[:, 1] = 0.10 + (v[:, 1] * 0.5 + 0.5) * 0.06
+    s.vertices = np.ascontiguousarray(v)
+    return s
+
+
+@pytest.mark.parametrize("bins", ["fixed", "exact"])
+def test_bin_overflow_is_repaired_or_reported(swr, oracle, monkeypatch, bins):
+    """Both bin layouts: k_bin's fixed tile regions (a crowded tile overflows its region) and the exact-size bins of the
+    four-kernel path (more (triangle,tile) pairs than the list holds)."""
+    if bins == "exact":
+        monkeypatch.setenv("SWR_BIN_MODE", "exact")
+        s = big_scene(swr)
+    else:
+        s = crowded_scene(swr)
     rc_c, rc_d, _, _ = oracle.render(s.vertices, s.indices, s.transform, s.width, s.height, DT | NC | oracle.TINV_PER_TRIANGLE)
     # (1) draw + present + wait: the overflowing frame is redrawn with grown bins and copied again
     with swr.Context() as ctx:
@@ -182,7 +200,7 @@ def test_bin_overflow_is_repaired_or_reported(swr, oracle):
         ctx.present(None, d)
         ctx.present_wait()
         same(None, d.array, None, rc_d, "overflow repaired at present_wait")
-        assert ctx.timings()["tile_pairs"] > 2 * s.triangles + 65536
+        assert ctx.timings()["tile_pairs"] > (2 * s.triangles + 65536 if bins == "exact" else s.triangles)
         d.free()
     # (2) an un-waited burst of PRESENTED frames: the earlier overflowing frame was rastered empty and copied to the
     # host like that -> reported once, bins grown, the last frame repaired

@@ -149,3 +149,40 @@ for lifo in (False, True):
     for tail in (False, True):
         report(f"repush 4px {'lifo' if lifo else 'fifo'}{' +tail' if tail else ''}", [sim_repush(l, 4, lifo, tail) for l in chunks])
 report("repush 8px fifo +tail", [sim_repush(l, 8, False, True) for l in chunks])
+
+# ---- two rings: spans (or remainders) of at most SMAX pixels wait in a ring of their own and are visited for SMAX pixels only
+def sim_two_rings(lanes, UPX=4, SMAX=2):
+    nl = len(lanes); ptr = [0] * nl
+    L, Sr = [], []
+    psteps = lsteps = ssteps = 0
+    def push(v):
+        (Sr if v <= SMAX else L).append(v)
+    while True:
+        while len(L) < 64 and len(Sr) < 64 and any(ptr[i] < len(lanes[i]) for i in range(nl)):
+            psteps += 1
+            for i in range(nl):
+                if ptr[i] < len(lanes[i]):
+                    if lanes[i][ptr[i]] > 0: push(int(lanes[i][ptr[i]]))
+                    ptr[i] += 1
+        rows_left = any(ptr[i] < len(lanes[i]) for i in range(nl))
+        if len(L) >= 64 or (not rows_left and L):
+            nq = min(len(L), 64)
+            J = 1 if len(L) >= 64 else 64 // pow2ge(nq)
+            popped, L = L[:nq], L[nq:]
+            for v in popped:
+                if v > UPX * J: push(v - UPX * J)
+            lsteps += 1
+        elif len(Sr) >= 64 or (not rows_left and Sr):
+            Sr = Sr[64:]
+            ssteps += 1
+        elif not rows_left:
+            break
+    return psteps, lsteps, ssteps
+
+for smax in (1, 2):
+    res = [sim_two_rings(l, 4, smax) for l in chunks]
+    sc_ = total_chunks / len(chunks)
+    ps = sum(r[0] for r in res) * sc_; ls = sum(r[1] for r in res) * sc_; ss = sum(r[2] for r in res) * sc_
+    cost_s = 17 + 17 * smax
+    print(f"  two rings, short = {smax} px: producer {ps / 1e3:.1f} K, long steps {ls / 1e3:.1f} K, short steps {ss / 1e3:.1f} K  "
+          f"-> consumer VALU {(ls * 93 + ss * cost_s) / 1e6:.2f} M  (one ring: {255.8e3 * 93 / 1e6:.2f} M)")

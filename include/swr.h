@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SWR_ABI_VERSION 3
+#define SWR_ABI_VERSION 4
 
 /* ---- status codes (the reference has no error channel: it fatalError()s / try!s,
  *      Renderer.swift:26,209,239,497; GpuRenderer.swift:20-31,37-38) ------------------ */
@@ -127,7 +127,16 @@ typedef struct swr_render_pass {
     const swr_material*    material;
     const void*            texture;     /* tex_width*tex_height Pixels (b,g,r,a), row-major; SWR_SHADER_TEXTURED_PHONG */
     int32_t  tex_width, tex_height;
-} swr_render_pass;
+    /* Scene identity (ABI 4).  The reference's only caller draws the SAME mesh every display frame with a new transform
+     * (App.swift:153-185) and its GpuRenderer keeps its device buffers across calls (GpuRenderer.swift:32-33,41-67).
+     * 0 = no promise: vertices / indices / attributes / texture are uploaded and the device-side triangle stream is
+     * rebuilt on every call (what ABI 3 did).  Non-zero = the caller promises that the CONTENT of `vertices`,
+     * `indices`, `attributes` and `texture` (and their counts / sizes) equals that of the last swr_render on this
+     * context that carried the same id: the upload is then skipped and the pass costs one resident frame plus the
+     * gather.  A new id (or new counts) uploads.  transform, flags, primitive_type, material and the image pointers
+     * may change freely between calls with the same id. */
+    uint64_t scene_id;
+} swr_render_pass;      /* 192 bytes */
 
 typedef struct swr_config {
     int32_t  device;        /* HIP device ordinal (of the first device); -1 = current device */
@@ -135,7 +144,14 @@ typedef struct swr_config {
                                on device (device + k) % min(N, visible devices), one host thread and one set of HIP
                                streams per band, scene replicated, no collective.  With fewer
                                visible GPUs than N, several bands share a GPU (same code path). */
-} swr_config;
+    uint32_t wait_budget_ms;/* Longest time any single wait inside the library may take (a helper thread polling for a
+                               kernel's completion, a blocking call waiting for the streams): 0 = default (20 000 ms).
+                               When it expires the context fails for good: the blocking call returns SWR_ERR_HIP with the
+                               frame number and what was being waited for, every later call returns the same error at
+                               once, swr_context_destroy still returns (it may leak what the GPU still owns).  The
+                               reference has no counterpart: scheduleAndWait blocks forever (Metal+Extensions.swift:57-67). */
+    uint32_t reserved;      /* 0 */
+} swr_config;               /* 16 bytes */
 
 /* Per-kernel device times of the last swr_draw / swr_render on this context, measured with
  * hipEvents recorded on the context's own stream (only filled when timing is enabled). */
@@ -168,8 +184,30 @@ void swr_context_destroy(swr_context* ctx);
 int  swr_context_bands(const swr_context* ctx);
 int  swr_context_band_info(const swr_context* ctx, int32_t band, int32_t* device, int64_t* row_begin, int64_t* row_end);
 
-/* Last error text for this context (NULL ctx: last error of a failed swr_context_create). */
+/* Last error text for this context (NULL ctx: last error of a failed swr_context_create).  Call it from the thread that
+ * made the failing call; the text stays valid until that thread's next call on the context. */
 const char* swr_last_error(const swr_context* ctx);
+
+/* Wall-clock phases of the last swr_render on this context (host steady clock; the H2D / stream-build split inside the
+ * upload comes from HIP events).  scene_cached = 1 when the pass carried the scene_id of the resident scene and nothing
+ * was uploaded. */
+typedef struct swr_render_times {
+    float h2d_ms;           /* vertices / indices / attributes / texture: host -> device */
+    float stream_build_ms;  /* index check, Morton order, de-indexed triangle stream, group boxes */
+    float draw_ms;          /* target + one frame, until the raster has finished */
+    float gather_ms;        /* swr_present + swr_present_wait: bands -> the caller's images */
+    float total_ms;
+    int32_t scene_cached;
+    int32_t reserved;
+} swr_render_times;
+int swr_render_timings(swr_context* ctx, swr_render_times* out);
+
+/* Fault injection for the failure-path tests (tests/test_gpu_api.py, tests/host): the NEXT frame's raster share
+ *   SWR_FAULT_LOST_EVENT   waits for a completion that never arrives (the wait budget must end it),
+ *   SWR_FAULT_ENQUEUE      fails as if a HIP launch had returned an error.
+ * Either way the context ends up failed (see swr_config.wait_budget_ms).  Never needed by a renderer. */
+enum { SWR_FAULT_NONE = 0, SWR_FAULT_LOST_EVENT = 1, SWR_FAULT_ENQUEUE = 2 };
+int swr_debug_fault(swr_context* ctx, int fault);
 
 /* Renderer.render(renderPass:) (Renderer.swift:204-230) and GpuRenderer.render(renderPass:)
  * (GpuRenderer.swift:35-90): caller-owned host memory in, colour + depth images filled on

@@ -23,6 +23,7 @@ ABI_SYMBOLS = [
     "swr_band_rows", "swr_scene_attributes", "swr_material_set", "swr_texture_upload",
     "swr_timing_sample", "swr_context_bands", "swr_context_band_info", "swr_host_alloc", "swr_host_free",
     "swr_host_register", "swr_host_unregister", "swr_present", "swr_present_wait", "swr_device_count",
+    "swr_render_timings", "swr_debug_fault",
 ]
 
 
@@ -44,6 +45,7 @@ class RenderPass(ctypes.Structure):
         ("transform", ctypes.c_float * 16),
         ("attributes", ctypes.c_void_p), ("material", ctypes.c_void_p), ("texture", ctypes.c_void_p),
         ("tex_width", ctypes.c_int32), ("tex_height", ctypes.c_int32),
+        ("scene_id", ctypes.c_uint64),        # ABI 4: non-zero = "same arrays as the last pass with this id": no upload
     ]
 
 
@@ -63,7 +65,20 @@ class Material(ctypes.Structure):
 
 
 class Config(ctypes.Structure):
-    _fields_ = [("device", ctypes.c_int32), ("device_count", ctypes.c_uint32)]
+    _fields_ = [("device", ctypes.c_int32), ("device_count", ctypes.c_uint32),
+                ("wait_budget_ms", ctypes.c_uint32), ("reserved", ctypes.c_uint32)]
+
+
+class RenderTimes(ctypes.Structure):
+    """swr_render_times: wall-clock phases of the last swr_render."""
+    _fields_ = [("h2d_ms", ctypes.c_float), ("stream_build_ms", ctypes.c_float), ("draw_ms", ctypes.c_float),
+                ("gather_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("scene_cached", ctypes.c_int32),
+                ("reserved", ctypes.c_int32)]
+
+    def as_dict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+
+FAULT_NONE, FAULT_LOST_EVENT, FAULT_ENQUEUE = 0, 1, 2
 
 
 class Timings(ctypes.Structure):
@@ -138,6 +153,10 @@ def load_library():
     L.swr_host_free.restype = None
     L.swr_host_register.argtypes = [vp, ctypes.c_size_t]
     L.swr_host_unregister.argtypes = [vp]
+    L.swr_render_timings.argtypes = [vp, ctypes.POINTER(RenderTimes)]
+    L.swr_render_timings.restype = ctypes.c_int
+    L.swr_debug_fault.argtypes = [vp, ctypes.c_int]
+    L.swr_debug_fault.restype = ctypes.c_int
     L.swr_present.argtypes = [vp, vp, vp]
     L.swr_present_wait.argtypes = [vp]
     for name in ("swr_context_bands", "swr_context_band_info", "swr_host_register", "swr_host_unregister", "swr_present",
@@ -187,8 +206,11 @@ class HostImage:
             raise SwrError(-7, f"swr_host_alloc({self.nbytes}) failed")
         buf = (ctypes.c_uint8 * self.nbytes).from_address(self.ptr)
         self.array = np.frombuffer(buf, dtype=self.dtype).reshape(self.shape)
+        self._busy = set()          # contexts with a present into this image in flight
 
     def free(self):
+        if self.ptr and self._busy:
+            raise SwrError(-1, "HostImage.free() while a swr_present into it is in flight: call present_wait() first")
         if self.ptr:
             self.array = None
             self._L.swr_host_free(self.ptr)
@@ -215,10 +237,11 @@ class Context:
     """swr_context: one per caller thread (GpuRenderer instance, App.swift:149); device_count > 1 = one context
     driving that many tile-row bands on as many GPUs as are visible."""
 
-    def __init__(self, device: int = -1, device_count: int = 0):
+    def __init__(self, device: int = -1, device_count: int = 0, wait_budget_ms: int = 0):
         self._L = load_library()
         self._h = ctypes.c_void_p()
-        cfg = Config(device, device_count)
+        self._present_refs = ()         # destinations of the presents in flight: kept alive until present_wait / close
+        cfg = Config(device, device_count, wait_budget_ms, 0)
         rc = self._L.swr_context_create(ctypes.byref(cfg), ctypes.byref(self._h))
         if rc:
             raise SwrError(rc, (self._L.swr_last_error(None) or b"").decode())
@@ -227,8 +250,9 @@ class Context:
 
     def close(self):
         if self._h:
-            self._L.swr_context_destroy(self._h)
+            self._L.swr_context_destroy(self._h)      # (waits for, or abandons, every copy in flight)
             self._h = ctypes.c_void_p()
+        self._release_presents()
 
     def __enter__(self):
         return self
@@ -317,12 +341,36 @@ class Context:
             if x is None:
                 return None
             return x.ptr if isinstance(x, HostImage) else x.ctypes.data
+        # the C side writes into these later (DMA, or the helper thread's staged memcpy): keep them alive until the copies
+        # have landed (a HostImage refuses to be freed meanwhile)
+        for x in (color, depth):
+            if isinstance(x, HostImage):
+                x._busy.add(id(self))
+        self._present_refs = self._present_refs + (color, depth)
         rc = self._L.swr_present(self._h, ptr(color), ptr(depth))
         if rc:
             self._check(rc)
 
+    def _release_presents(self):
+        for x in self._present_refs:
+            if isinstance(x, HostImage):
+                x._busy.discard(id(self))
+        self._present_refs = ()
+
     def present_wait(self):
-        self._check(self._L.swr_present_wait(self._h))
+        try:
+            self._check(self._L.swr_present_wait(self._h))
+        finally:
+            self._release_presents()
+
+    def render_timings(self) -> dict:
+        t = RenderTimes()
+        self._check(self._L.swr_render_timings(self._h, ctypes.byref(t)))
+        return t.as_dict()
+
+    def debug_fault(self, fault: int):
+        """Fault injection for the failure-path tests (FAULT_LOST_EVENT / FAULT_ENQUEUE)."""
+        self._check(self._L.swr_debug_fault(self._h, int(fault)))
 
     def read_color(self, out: np.ndarray | None = None) -> np.ndarray:
         if out is None:
@@ -367,7 +415,7 @@ class Context:
 
     # -- one-shot path: Renderer.render(renderPass:) / GpuRenderer.render(renderPass:) -----
     def render(self, vertices, indices, transform, width, height, flags=0, primitive_type=0,
-               color=None, depth=None, shading=None):
+               color=None, depth=None, shading=None, scene_id=0):
         v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 8)
         i = np.ascontiguousarray(indices, dtype=np.int64).reshape(-1)
         m = np.ascontiguousarray(transform, dtype=np.float32).reshape(16)
@@ -384,6 +432,7 @@ class Context:
         rp.vertices, rp.vertex_count = v.ctypes.data, v.shape[0]
         rp.indices, rp.index_count = i.ctypes.data, i.size
         rp.primitive_type, rp.flags = primitive_type, flags
+        rp.scene_id = int(scene_id)
         rp.transform = (ctypes.c_float * 16)(*m.tolist())
         if shading is not None:
             a = np.ascontiguousarray(shading.attrs, dtype=np.float32).reshape(-1, 8)

@@ -36,6 +36,9 @@ using namespace swr;
 
 namespace {
 thread_local std::string g_create_error;
+// true on a context's own helper threads (bin_worker / ras_worker): an error there cannot be written into the context's
+// error string — the caller may be reading it (swr_last_error) — and is fatal for the context anyway
+thread_local bool tl_helper_thread = false;
 
 struct DevBuf {
     void* p = nullptr;
@@ -53,8 +56,9 @@ struct Worker {
     bool busy = false, quit = false;
     int sticky_rc = 0;
 
-    void start(int device) {
-        th = std::thread([this, device] {
+    void start(int device, bool helper = false) {
+        th = std::thread([this, device, helper] {
+            tl_helper_thread = helper;
             (void)hipSetDevice(device);
             std::unique_lock<std::mutex> lk(m);
             for (;;) {
@@ -110,13 +114,31 @@ struct Worker {
 };
 }  // namespace
 
-static_assert(sizeof(swr_render_pass) == 184 && sizeof(swr_material) == 56 && sizeof(swr_vertex_attr) == 32 &&
-              sizeof(swr_vertex) == 32 && sizeof(swr_config) == 8, "include/swr.h layouts (mirrored by the ctypes / Swift bindings)");
+static_assert(sizeof(swr_render_pass) == 192 && sizeof(swr_material) == 56 && sizeof(swr_vertex_attr) == 32 &&
+              sizeof(swr_vertex) == 32 && sizeof(swr_config) == 16 && sizeof(swr_render_times) == 28,
+              "include/swr.h layouts (mirrored by the ctypes / Swift bindings)");
 
 struct swr_context {
     int device = 0;
     hipStream_t stream = nullptr;
-    std::string err;
+    std::string err;                    // written and read on the caller's thread only (swr_last_error)
+
+    // ---- failure state: a HIP error while a helper thread enqueues, or a wait that outlives the budget, fails the
+    // context for good.  `failed` is what every spin loop, every later call and the destructor look at; the text is
+    // written once under the mutex (by whichever thread failed) and copied into `err` by the caller's thread.
+    std::atomic<int> failed{0};
+    std::mutex err_m;
+    std::string failed_msg;
+    uint32_t wait_budget_ms = 20000;
+    std::atomic<int> inject{0};         // swr_debug_fault: consumed by the next frame's raster share
+    // scene identity of swr_render (swr_render_pass.scene_id): what is resident
+    uint64_t scene_id = 0;
+    int64_t scene_nv = -1, scene_ni = -1;
+    bool scene_attrs = false;
+    const void* scene_tex = nullptr; int32_t scene_tw = 0, scene_th = 0;
+    swr_render_times rt{};              // phases of the last swr_render
+    float up_h2d_ms = 0.0f, up_build_ms = 0.0f;   // of the last swr_scene_upload (HIP events)
+    hipEvent_t up_ev[3] = {nullptr, nullptr, nullptr};
 
     // ---- group (device_count > 1): the sub-contexts and their host threads; nothing below is used by a group ----
     std::vector<swr_context*> kids;
@@ -283,15 +305,59 @@ struct swr_context {
 
 namespace {
 
+// The context has failed for good (first failure wins).  Callable from any thread.
+int fatal_msg(swr_context* c, int code, const char* text) {
+    std::lock_guard<std::mutex> lk(c->err_m);
+    if (!c->failed.load(std::memory_order_relaxed)) {
+        c->failed_msg = text;
+        c->failed.store(code, std::memory_order_release);
+    }
+    return code;
+}
+
 int fail(swr_context* c, int code, const char* fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (c) c->err = buf; else g_create_error = buf;
+    if (!c) g_create_error = buf;
+    else if (tl_helper_thread) return fatal_msg(c, code, buf);    // never touch c->err from a helper (the caller may be reading it)
+    else c->err = buf;
     return code;
 }
+
+int fatal(swr_context* c, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    return fatal_msg(c, code, buf);
+}
+
+// Caller's thread: has the context failed?  Then its text becomes the last error and every entry point returns the code.
+int sticky(swr_context* c) {
+    const int f = c->failed.load(std::memory_order_acquire);
+    if (f) {
+        std::lock_guard<std::mutex> lk(c->err_m);
+        c->err = c->failed_msg;
+    }
+    return f;
+}
+
+// Bounded waiting: spin, then yield, never beyond the context's budget; gives up at once when the context has failed.
+struct Deadline {
+    std::chrono::steady_clock::time_point end;
+    unsigned spins = 0;
+    explicit Deadline(const swr_context* c) : end(std::chrono::steady_clock::now() + std::chrono::milliseconds(c->wait_budget_ms)) {}
+    // false: the budget is used up
+    bool pause() {
+        if (++spins < 2000) { for (int i = 0; i < 8; i++) __builtin_ia32_pause(); return true; }
+        std::this_thread::yield();
+        return (spins & 63u) != 0 || std::chrono::steady_clock::now() < end;
+    }
+};
 
 #define HIP_TRY(ctx, expr)                                                                     \
     do {                                                                                       \
@@ -336,31 +402,63 @@ int ensure_capacity(swr_context* c, uint32_t cap) {
 int flush_raster(swr_context* c, uint64_t upto_frame_count);
 int enqueue_raster_shares(swr_context* c, uint64_t upto_frame_count);
 
-// hipEventQuery until the event has completed (host-paced ordering: see swr_context::ras_worker)
-int poll_event(swr_context* c, hipEvent_t ev) {
-    for (unsigned spins = 0;;) {
-        const hipError_t e = hipEventQuery(ev);
+// hipEventQuery until the event has completed (host-paced ordering: see swr_context::ras_worker) — or the context has
+// failed, or the wait budget is used up: then the context fails with what was being waited for.
+int poll_event(swr_context* c, hipEvent_t ev, const char* what, uint64_t frame, bool never = false) {
+    Deadline d(c);
+    for (;;) {
+        if (const int f = c->failed.load(std::memory_order_acquire)) return f;
+        const hipError_t e = never ? hipErrorNotReady : hipEventQuery(ev);
         if (e == hipSuccess) return SWR_OK;
-        if (e != hipErrorNotReady) { HIP_TRY(c, e); }
-        (void)hipGetLastError();                  // hipErrorNotReady is sticky in hipGetLastError
-        if (++spins > 20000) std::this_thread::yield();   // more spinning threads than cores (many bands on one box)
-        else for (int i = 0; i < 8; i++) __builtin_ia32_pause();
+        if (e != hipErrorNotReady) return fatal(c, SWR_ERR_HIP, "hipEventQuery(%s of frame %llu) failed: %s", what, (unsigned long long)frame, hipGetErrorString(e));
+        if (!never) (void)hipGetLastError();                  // hipErrorNotReady is sticky in hipGetLastError
+        if (!d.pause())
+            return fatal(c, SWR_ERR_HIP, "frame %llu: %s did not complete within %u ms (device %d); the context has failed",
+                         (unsigned long long)frame, what, c->wait_budget_ms, c->device);
     }
+}
+
+// hipStreamSynchronize with the same bound (hipStreamQuery polls)
+int wait_stream(swr_context* c, hipStream_t s, const char* what) {
+    Deadline d(c);
+    for (;;) {
+        if (const int f = c->failed.load(std::memory_order_acquire)) return f;
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return SWR_OK;
+        if (e != hipErrorNotReady) return fatal(c, SWR_ERR_HIP, "hipStreamQuery(%s) failed: %s", what, hipGetErrorString(e));
+        (void)hipGetLastError();
+        if (!d.pause())
+            return fatal(c, SWR_ERR_HIP, "the %s did not drain within %u ms (device %d, %llu frames drawn); the context has failed",
+                         what, c->wait_budget_ms, c->device, (unsigned long long)c->frame_no);
+    }
+}
+
+// wait until an atomic frame counter has passed `g` (the other helper's progress)
+int wait_counter(swr_context* c, const std::atomic<uint64_t>& ctr, uint64_t g, const char* what) {
+    Deadline d(c);
+    while (ctr.load(std::memory_order_acquire) <= g) {
+        if (const int f = c->failed.load(std::memory_order_acquire)) return f;
+        if (!d.pause())
+            return fatal(c, SWR_ERR_HIP, "frame %llu: %s was not enqueued within %u ms; the context has failed", (unsigned long long)g, what, c->wait_budget_ms);
+    }
+    return SWR_OK;
 }
 
 int sync_streams(swr_context* c) {
     int rc = flush_raster(c, c->frame_no);      // everything drawn so far is on the streams
-    if (rc) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->bin_stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if (!rc) rc = wait_stream(c, c->bin_stream, "binning stream");
+    if (!rc) rc = wait_stream(c, c->stream, "raster stream");
+    if (rc) return sticky(c) ? sticky(c) : rc;
     c->synced_upto = c->posted;      // NOT frame_no: enqueue_frame may sync after it has numbered the frame it is about to post
     return SWR_OK;
 }
 
 int sync_copies(swr_context* c) {
-    if (c->ras_worker) { const int rc = c->ras_worker->drain(); if (rc) return rc; }   // posted swr_present copies
-    HIP_TRY(c, hipStreamSynchronize(c->copy_stream[0]));
-    HIP_TRY(c, hipStreamSynchronize(c->copy_stream[1]));
+    int rc = SWR_OK;
+    if (c->ras_worker) rc = c->ras_worker->drain();    // posted swr_present copies
+    if (!rc) rc = wait_stream(c, c->copy_stream[0], "colour copy stream");
+    if (!rc) rc = wait_stream(c, c->copy_stream[1], "depth copy stream");
+    if (rc) return sticky(c) ? sticky(c) : rc;
     return SWR_OK;
 }
 
@@ -391,7 +489,7 @@ int size_bins(swr_context* c) {
             HIP_TRY(c, hipMemsetAsync(c->fillbuf[k].p, 0, c->fillbuf[k].bytes, c->stream));
             c->fill_dirty[k] = false;
         }
-        HIP_TRY(c, hipStreamSynchronize(c->stream));
+        if ((rc = wait_stream(c, c->stream, "raster stream (fill counters)"))) return sticky(c) ? sticky(c) : rc;
         c->fixed_mode = true;
         return SWR_OK;
     }
@@ -476,6 +574,7 @@ int wait_for_copies_of(swr_context* c, int fb, hipStream_t s) {
 }
 
 int enqueue_frame(swr_context* c) {
+    if (const int f = sticky(c)) return f;      // a failed context posts nothing more
     c->hp_begin();
     {
         const BinPlan plan = plan_binning(c->ni / 3, tiles_of(c->tg));
@@ -573,7 +672,7 @@ int enqueue_frame(swr_context* c) {
     // settles it: every non-pipelined path syncs first)
     const bool slot_wait = sb != sr && frame >= (uint64_t)swr_context::NSLOT && frame - (uint64_t)swr_context::NSLOT >= c->synced_upto;
     // helpers or the caller's own thread?  (idle context: every earlier frame is complete)
-    const bool streaming = sb != sr && c->bin_worker && !(c->inline_idle && c->synced_upto == c->posted);
+    const bool streaming = sb != sr && (c->bin_worker || c->ras_worker) && !(c->inline_idle && c->synced_upto == c->posted);
     const bool paced = streaming && c->ras_worker != nullptr;      // cross-stream order by host polls instead of event waits
     auto bin_share = [c, f, si, sb, sr, frame, zero_tables, zero_bytes, e0, e1, e2, sort_on_raster_stream, slot_wait, paced, fill_memset]() -> int {
         swr_context::Slot& sl = c->slot[si];
@@ -582,11 +681,10 @@ int enqueue_frame(swr_context* c) {
             // recorded (by ras_worker or the caller's thread) before it is polled / waited for
             const uint64_t prev = frame - (uint64_t)swr_context::NSLOT;
             const uint64_t ef = prev + (uint64_t)(swr_context::RAS_EVERY - 1) - prev % (uint64_t)swr_context::RAS_EVERY;
-            for (unsigned spins = 0; c->ras_enqueued.load(std::memory_order_acquire) <= ef;)
-                if (++spins > 100000) std::this_thread::yield(); else __builtin_ia32_pause();
+            { const int rc = wait_counter(c, c->ras_enqueued, ef, "the raster of an earlier frame"); if (rc) return rc; }
             swr_context::Slot& es = c->slot[ef % (uint64_t)swr_context::NSLOT];
             if (es.ras_event_frame == ef) {
-                if (paced) { const int rc = poll_event(c, es.ras_done); if (rc) return rc; }
+                if (paced) { const int rc = poll_event(c, es.ras_done, "k_raster (its working set is needed again)", ef); if (rc) return rc; }
                 else HIP_TRY(c, hipStreamWaitEvent(sb, es.ras_done, 0));
             }
         }
@@ -615,7 +713,10 @@ int enqueue_frame(swr_context* c) {
         HIP_TRY(c, hipGetLastError());
         return SWR_OK;
     };
-    while (c->ras_enqueued.load(std::memory_order_acquire) + (uint64_t)swr_context::RAS_RING <= frame) std::this_thread::yield();
+    if (frame >= (uint64_t)swr_context::RAS_RING) {
+        const int rc = wait_counter(c, c->ras_enqueued, frame - (uint64_t)swr_context::RAS_RING, "the raster share of an earlier frame");
+        if (rc) { c->frame_no = frame; return sticky(c) ? sticky(c) : rc; }     // nothing was posted for this frame
+    }
     swr_context::RasJob& rj = c->ras_job[frame % swr_context::RAS_RING];
     rj.f = f; rj.ev3 = ev ? ev[3] : nullptr; rj.ev4 = ev ? ev[4] : nullptr; rj.si = si; rj.sort_here = sort_on_raster_stream;
     rj.fb = c->fb_cur;
@@ -623,13 +724,20 @@ int enqueue_frame(swr_context* c) {
     c->draw_pending = true;   // the pair total lands in the frame's pinned word (written by the scan)
     c->posted = frame + 1;
     if (streaming) {
-        // two threads: the helper enqueues this frame's binning while this thread enqueues the previous frame's raster
-        c->bin_worker->post([c, bin_share, frame]() -> int {
-            const int rc = bin_share();
-            if (rc) c->bin_error.store(rc, std::memory_order_relaxed);
+        // two helpers: one enqueues this frame's binning while the other enqueues the previous frame's raster.  One
+        // helper (sub-contexts of a group: the group's per-device thread is this thread): the binning share runs here.
+        auto bin_job = [c, bin_share, frame]() -> int {
+            int rc = c->failed.load(std::memory_order_acquire);
+            if (!rc) rc = bin_share();
+            if (rc) {
+                fatal(c, rc, "enqueueing the binning of frame %llu failed: %s", (unsigned long long)frame, tl_helper_thread ? "(helper thread)" : c->err.c_str());
+                c->bin_error.store(rc, std::memory_order_relaxed);
+            }
             c->bin_enqueued.store(frame + 1, std::memory_order_release);
             return rc;
-        });
+        };
+        if (c->bin_worker) c->bin_worker->post(bin_job);
+        else (void)bin_job();                    // a failure is picked up by the raster share (bin_error) and by the next blocking call
         c->hp_lap(2);
         if (c->ras_worker) {
             c->ras_worker->post([c, frame]() -> int { return enqueue_raster_shares(c, frame + 1); });
@@ -652,38 +760,57 @@ int flush_raster(swr_context* c, uint64_t upto) {
     return enqueue_raster_shares(c, std::min(upto, c->posted));   // frames of the one-stream path (never posted)
 }
 
-// The raster stream's share of every frame below `upto` that has not been enqueued yet (caller's thread or ras_worker).
+// The raster stream's share of frame g (caller's thread or ras_worker).
+int raster_share(swr_context* c, uint64_t g) {
+    { const int rc = wait_counter(c, c->bin_enqueued, g, "the binning share"); if (rc) return rc; }
+    if (c->bin_error.load(std::memory_order_relaxed)) {
+        const int rc = c->bin_error.exchange(0);
+        return rc ? rc : SWR_ERR_HIP;          // the text was recorded by the thread that failed
+    }
+    swr_context::RasJob& rj = c->ras_job[g % swr_context::RAS_RING];
+    swr_context::Slot& sl = c->slot[rj.si];
+    hipStream_t sb = c->bin_stream, sr = c->stream;
+    const int inj = c->inject.exchange(0, std::memory_order_relaxed);      // swr_debug_fault
+    if (inj == SWR_FAULT_ENQUEUE) return fatal(c, SWR_ERR_HIP, "frame %llu: injected enqueue failure (swr_debug_fault)", (unsigned long long)g);
+    c->hp_begin_r();
+    if (sb != sr) {
+        if (rj.paced || inj == SWR_FAULT_LOST_EVENT) {
+            const int rc = poll_event(c, sl.bin_done, "the binning (k_bin / k_sort_bins)", g, inj == SWR_FAULT_LOST_EVENT);
+            if (rc) return rc;
+        } else HIP_TRY(c, hipStreamWaitEvent(sr, sl.bin_done, 0));
+    } else if (inj == SWR_FAULT_LOST_EVENT) {
+        const int rc = poll_event(c, sl.bin_done, "the binning (k_bin / k_sort_bins)", g, true);
+        if (rc) return rc;
+    }
+    c->hp_lap_r(3);
+    { int rc = wait_for_copies_of(c, rj.fb, sr); if (rc) return rc; }
+    if (rj.sort_here) launch_sort_bins(rj.f, sr);
+    if (rj.ev3) HIP_TRY(c, hipEventRecord(rj.ev3, sr));
+    const bool carries = sb != sr && g % (uint64_t)swr_context::RAS_EVERY == (uint64_t)(swr_context::RAS_EVERY - 1);
+    const bool bound = launch_raster(rj.f, sr, (carries && c->bind_events) ? sl.ras_done : nullptr);
+    if (rj.ev4) HIP_TRY(c, hipEventRecord(rj.ev4, sr));
+    c->hp_lap_r(4);
+    if (carries) { if (!bound) HIP_TRY(c, hipEventRecord(sl.ras_done, sr)); sl.ras_event_frame = g; }
+    c->hp_lap_r(5);
+    c->hp_frames++;
+    HIP_TRY(c, hipGetLastError());
+    return SWR_OK;
+}
+
+// The raster shares of every frame below `upto` that have not been enqueued yet.  ANY failure fails the context and
+// still advances ras_enqueued: the binning helper (slot wait), swr_draw (back-pressure) and the destructor wait on it.
 int enqueue_raster_shares(swr_context* c, uint64_t upto) {
     for (;;) {
         const uint64_t g = c->ras_enqueued.load(std::memory_order_relaxed);
         if (g >= upto) return SWR_OK;
-        for (unsigned spins = 0; c->bin_enqueued.load(std::memory_order_acquire) <= g;)
-            if (++spins > 100000) std::this_thread::yield(); else __builtin_ia32_pause();
-        if (c->bin_error.load(std::memory_order_relaxed)) {
-            const int rc = c->bin_error.exchange(0);
-            c->ras_enqueued.store(upto, std::memory_order_release);
-            return rc ? rc : SWR_ERR_HIP;          // c->err was set by the helper
+        int rc = c->failed.load(std::memory_order_acquire);
+        if (!rc) rc = raster_share(c, g);
+        if (rc) {
+            // (no-op when the cause has been recorded already: a helper's HIP_TRY, an expired wait)
+            fatal(c, rc, "enqueueing the raster of frame %llu failed: %s", (unsigned long long)g, tl_helper_thread ? "(helper thread)" : c->err.c_str());
+            c->ras_enqueued.store(std::max(upto, g + 1), std::memory_order_release);
+            return rc;
         }
-        swr_context::RasJob& rj = c->ras_job[g % swr_context::RAS_RING];
-        swr_context::Slot& sl = c->slot[rj.si];
-        hipStream_t sb = c->bin_stream, sr = c->stream;
-        c->hp_begin_r();
-        if (sb != sr) {
-            if (rj.paced) { const int rc = poll_event(c, sl.bin_done); if (rc) return rc; }
-            else HIP_TRY(c, hipStreamWaitEvent(sr, sl.bin_done, 0));
-        }
-        c->hp_lap_r(3);
-        { int rc = wait_for_copies_of(c, rj.fb, sr); if (rc) return rc; }
-        if (rj.sort_here) launch_sort_bins(rj.f, sr);
-        if (rj.ev3) HIP_TRY(c, hipEventRecord(rj.ev3, sr));
-        const bool carries = sb != sr && g % (uint64_t)swr_context::RAS_EVERY == (uint64_t)(swr_context::RAS_EVERY - 1);
-        const bool bound = launch_raster(rj.f, sr, (carries && c->bind_events) ? sl.ras_done : nullptr);
-        if (rj.ev4) HIP_TRY(c, hipEventRecord(rj.ev4, sr));
-        c->hp_lap_r(4);
-        if (carries) { if (!bound) HIP_TRY(c, hipEventRecord(sl.ras_done, sr)); sl.ras_event_frame = g; }
-        c->hp_lap_r(5);
-        c->hp_frames++;
-        HIP_TRY(c, hipGetLastError());
         c->ras_enqueued.store(g + 1, std::memory_order_release);
     }
 }
@@ -735,7 +862,7 @@ int copy_band(swr_context* c, int fb, int img, void* dst_full) {
             }
             if (k > 0) {
                 const size_t j = k - 1, len = std::min(CH, bytes - j * CH);
-                HIP_TRY(c, hipEventSynchronize(c->stage_ev[img][j & 1]));
+                { const int rcw = poll_event(c, c->stage_ev[img][j & 1], "a staged copy to the host", c->frame_no); if (rcw) return rcw; }
                 memcpy(dst + j * CH, c->stage[img][j & 1], len);
             }
         }
@@ -751,15 +878,17 @@ int enqueue_present(swr_context* c, void* color_full, float* depth_full);
 
 int single_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_count,
                         const int64_t* indices, int64_t index_count) {
+    if (const int f = sticky(c)) return f;
     if (vertex_count < 0 || index_count < 0 || (index_count > 0 && (!indices || !vertices)))
         return fail(c, SWR_ERR_BAD_ARG, "swr_scene_upload: bad vertex/index arguments");
     if (index_count / 3 >= 0xFFFFFFFFll || vertex_count > 0xFFFFFFFFll)
         return fail(c, SWR_ERR_UNSUPPORTED, "more than 2^32-2 primitives or 2^32 vertices");
     HIP_TRY(c, hipSetDevice(c->device));
-    { int rcs = sync_streams(c); if (rcs) return rcs; }
+    { int rcs = check_frames(c); if (rcs) return rcs; }     // (an overflowed frame presented just before is repaired / reported first)
     c->has_scene = false;
     c->has_attrs = false;
     c->draw_pending = false;
+    c->present_pending = false;
     int rc;
     if ((rc = ensure(c, c->vertices, (size_t)vertex_count * sizeof(swr_vertex)))) return rc;
     if ((rc = ensure(c, c->indices, (size_t)index_count * 8))) return rc;
@@ -782,11 +911,14 @@ int single_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vert
         if ((rc = ensure(c, sl.live, (size_t)((index_count / 3 + 63) / 64 + 2 * 1024 + 2) * 4))) return rc;   // [G <= 1024][1 + per]
         if ((rc = ensure(c, sl.tilebuf, (size_t)(CNT_WORDS + 3 * std::max(1, tiles_of(c->tg)) + 1) * 4))) return rc;
     }
+    for (auto& e : c->up_ev) if (!e) HIP_TRY(c, hipEventCreate(&e));
+    HIP_TRY(c, hipEventRecord(c->up_ev[0], c->stream));
     if (vertex_count)
         HIP_TRY(c, hipMemcpyAsync(c->vertices.p, vertices, (size_t)vertex_count * sizeof(swr_vertex),
                                   hipMemcpyHostToDevice, c->stream));
     if (index_count)
         HIP_TRY(c, hipMemcpyAsync(c->indices.p, indices, (size_t)index_count * 8, hipMemcpyHostToDevice, c->stream));
+    HIP_TRY(c, hipEventRecord(c->up_ev[1], c->stream));
     // index range check (Swift array subscript would trap, Renderer.swift:226)
     HIP_TRY(c, hipMemsetAsync(c->slot[0].tilebuf.p, 0, CNT_WORDS * 4, c->stream));
     launch_validate_indices((const int64_t*)c->indices.p, index_count, vertex_count, (uint32_t*)c->slot[0].tilebuf.p, c->stream);
@@ -804,7 +936,10 @@ int single_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vert
         c->reordered = ntri > 0 && ntri < SORT_MAX_TRIS && sort_mode != -1;   // original index travels in GeomRec.flags
     }
     HIP_TRY(c, hipMemcpyAsync(c->h_misc, c->slot[0].tilebuf.p, CNT_WORDS * 4, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    HIP_TRY(c, hipEventRecord(c->up_ev[2], c->stream));
+    if ((rc = wait_stream(c, c->stream, "scene upload"))) return sticky(c) ? sticky(c) : rc;
+    (void)hipEventElapsedTime(&c->up_h2d_ms, c->up_ev[0], c->up_ev[1]);
+    (void)hipEventElapsedTime(&c->up_build_ms, c->up_ev[1], c->up_ev[2]);
     if (c->h_misc[CNT_BAD_INDEX])
         return fail(c, SWR_ERR_INDEX_RANGE, "an index is outside [0, %lld)", (long long)vertex_count);
     c->nv = vertex_count;
@@ -821,6 +956,7 @@ int single_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vert
 }
 
 int single_scene_attributes(swr_context* c, const swr_vertex_attr* attributes, int64_t vertex_count) {
+    if (const int f = sticky(c)) return f;
     if (!c->has_scene) return fail(c, SWR_ERR_NO_SCENE, "swr_scene_attributes needs swr_scene_upload first");
     if (vertex_count != c->nv || (vertex_count > 0 && !attributes))
         return fail(c, SWR_ERR_BAD_ARG, "swr_scene_attributes: %lld attributes for %lld vertices",
@@ -836,7 +972,7 @@ int single_scene_attributes(swr_context* c, const swr_vertex_attr* attributes, i
     launch_gather_attrs((const swr_vertex_attr*)c->attrs.p, vertex_count, (const int64_t*)c->indices.p, c->ni / 3,
                         (const float4*)c->tri_xyz.p, (float4*)c->tri_nrm.p, (float4*)c->tri_rgb.p, c->stream);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if ((rc = wait_stream(c, c->stream, "attribute upload"))) return sticky(c) ? sticky(c) : rc;
     c->has_attrs = true;
     return SWR_OK;
 }
@@ -852,6 +988,7 @@ int single_material_set(swr_context* c, const swr_material* m) {
 }
 
 int single_texture_upload(swr_context* c, const void* bgra8, int32_t width, int32_t height) {
+    if (const int f = sticky(c)) return f;
     if (!bgra8 || width <= 0 || height <= 0 || width > 16384 || height > 16384)
         return fail(c, SWR_ERR_BAD_ARG, "swr_texture_upload: bad texture %dx%d", width, height);
     HIP_TRY(c, hipSetDevice(c->device));
@@ -863,7 +1000,7 @@ int single_texture_upload(swr_context* c, const void* bgra8, int32_t width, int3
     HIP_TRY(c, hipMemcpyAsync(c->texture_bytes.p, bgra8, n * 4, hipMemcpyHostToDevice, c->stream));
     launch_texture_to_float((const uint32_t*)c->texture_bytes.p, (int64_t)n, (float4*)c->texture.p, c->stream);
     HIP_TRY(c, hipGetLastError());
-    HIP_TRY(c, hipStreamSynchronize(c->stream));
+    if ((rc = wait_stream(c, c->stream, "texture upload"))) return sticky(c) ? sticky(c) : rc;
     c->tex_w = width; c->tex_h = height;
     return SWR_OK;
 }
@@ -878,10 +1015,13 @@ int check_target_args(swr_context* c, int64_t width, int64_t height, int64_t row
 }
 
 int single_target_set(swr_context* c, int64_t width, int64_t height, int64_t row_begin, int64_t row_end) {
+    if (const int f = sticky(c)) return f;
     int rc = check_target_args(c, width, height, row_begin, row_end);
     if (rc) return rc;
     HIP_TRY(c, hipSetDevice(c->device));
-    if ((rc = sync_streams(c)) || (rc = sync_copies(c))) return rc;
+    if (c->has_target && c->tg.width == width && c->tg.height == height && c->tg.row_begin == row_begin && c->tg.row_end == row_end)
+        return SWR_OK;          // the same target again (swr_render every frame): nothing to resize, nothing to wait for
+    if ((rc = check_frames(c)) || (rc = sync_copies(c))) return rc;      // (an overflowed frame presented just before is repaired / reported first)
     c->draw_pending = false;
     c->present_pending = false;
     Target t;
@@ -967,6 +1107,7 @@ int enqueue_present(swr_context* c, void* color_full, float* depth_full) {
 }
 
 int single_present(swr_context* c, void* color_full, float* depth_full) {
+    if (const int f = sticky(c)) return f;
     if (!c->has_target) return fail(c, SWR_ERR_NO_SCENE, "swr_present needs swr_target_set and a swr_draw first");
     if (!color_full && !depth_full) return fail(c, SWR_ERR_BAD_ARG, "swr_present: both image pointers are NULL");
     HIP_TRY(c, hipSetDevice(c->device));
@@ -1037,6 +1178,7 @@ int check_frames(swr_context* c) {
         }
         if (pairs <= old_limit) {
             c->draw_pending = false;
+            c->present_pending = false;        // the last frame is verified: a later repair must not copy into a stale destination
             c->frames_checked = c->frame_no;
             c->last.tile_pairs = pair_word(c, L);
             c->last.tiles = tiles_of(c->tg);
@@ -1044,19 +1186,22 @@ int check_frames(swr_context* c) {
             return finish();
         }
         // the last frame overflowed: redraw it into the same framebuffer, copy it again
+        const bool was_presented = c->present_pending && c->frame_presented[L % swr_context::PAIR_RING];
         c->fb_cur = c->fb_last;
         if ((rc = enqueue_frame(c))) return rc;
-        if (c->present_pending && (rc = enqueue_present(c, c->present_color, c->present_depth))) return rc;
+        if (was_presented && (rc = enqueue_present(c, c->present_color, c->present_depth))) return rc;
     }
     return fail(c, SWR_ERR_HIP, "pair list kept overflowing");
 }
 
 int single_sync(swr_context* c) {
+    if (const int f = sticky(c)) return f;
     HIP_TRY(c, hipSetDevice(c->device));
     return check_frames(c);
 }
 
 int single_present_wait(swr_context* c) {
+    if (const int f = sticky(c)) return f;
     HIP_TRY(c, hipSetDevice(c->device));
     int rc = check_frames(c);
     if (rc) return rc;
@@ -1066,6 +1211,7 @@ int single_present_wait(swr_context* c) {
 }
 
 int single_read(swr_context* c, int img, void* dst) {
+    if (const int f = sticky(c)) return f;
     if (!c->has_target) return fail(c, SWR_ERR_NO_SCENE, "swr_read_* needs swr_target_set first");
     int rc = single_sync(c);
     if (rc) return rc;
@@ -1073,17 +1219,35 @@ int single_read(swr_context* c, int img, void* dst) {
     const int fb = c->fb_last;
     HIP_TRY(c, hipEventRecord(c->frame_done[fb], c->stream));
     if ((rc = copy_band(c, fb, img, dst))) return rc;
-    HIP_TRY(c, hipStreamSynchronize(c->copy_stream[img]));
+    if ((rc = wait_stream(c, c->copy_stream[img], "copy stream"))) return sticky(c) ? sticky(c) : rc;
     return SWR_OK;
 }
 
 void destroy_single(swr_context* c) {
     hipSetDevice(c->device);
+    // helper jobs are bounded (every wait in them is) and give up at once on a failed context: the drains return
     if (c->ras_worker) { c->ras_worker->drain(); c->ras_worker->stop(); delete c->ras_worker; c->ras_worker = nullptr; }
     if (c->bin_worker) { c->bin_worker->drain(); c->bin_worker->stop(); delete c->bin_worker; c->bin_worker = nullptr; }
-    if (c->bin_stream) hipStreamSynchronize(c->bin_stream);
-    if (c->stream) hipStreamSynchronize(c->stream);
-    for (int i = 0; i < 2; i++) if (c->copy_stream[i]) hipStreamSynchronize(c->copy_stream[i]);
+    // bounded too: a GPU that never finishes must not hang the destructor (what it still owns is then leaked)
+    c->wait_budget_ms = std::min<uint32_t>(c->wait_budget_ms, 5000u);
+    auto drain = [c](hipStream_t st) {           // (looks at the stream, not at the failed flag: the GPU may be fine)
+        if (!st) return true;
+        Deadline d(c);
+        for (;;) {
+            const hipError_t e = hipStreamQuery(st);
+            if (e == hipSuccess) return true;
+            if (e != hipErrorNotReady) return false;
+            (void)hipGetLastError();
+            if (!d.pause()) return false;
+        }
+    };
+    const bool drained = drain(c->bin_stream) && drain(c->stream) && drain(c->copy_stream[0]) && drain(c->copy_stream[1]);
+    if (!drained) {
+        fprintf(stderr, "[swr] context on device %d destroyed in a failed state (%s); device memory it may still be using is not freed\n",
+                c->device, c->failed_msg.c_str());
+        delete c;
+        return;
+    }
     if (c->hp_on && c->hp_frames)
         fprintf(stderr, "[swr host profile] device %d, %llu frames, us/frame: prepare %.2f | wait(slot) %.2f | binning launches %.2f | "
                         "event record+wait %.2f | raster-stream launches %.2f | record(ras_done) %.2f\n", c->device,
@@ -1114,13 +1278,18 @@ void destroy_single(swr_context* c) {
     if (c->ev_ok)
         for (int r = 0; r < swr_context::RING; r++)
             for (int i = 0; i < 5; i++) hipEventDestroy(c->ev[r][i]);
+    for (auto& e : c->up_ev) if (e) hipEventDestroy(e);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
 
-int create_single(int dev, swr_context** out) {
+// helpers: 2 = a binning and a raster helper (a single-device context), 1 = the raster helper only — the thread that
+// calls swr_draw enqueues the binning itself (sub-contexts of a group: that thread is the group's per-device worker, so
+// a device has ONE thread that polls for completions, not two), 0 = none.
+int create_single(int dev, swr_context** out, int helpers, uint32_t wait_budget_ms) {
     swr_context* c = new swr_context();
     c->device = dev;
+    if (wait_budget_ms) c->wait_budget_ms = wait_budget_ms;
     c->hp_on = getenv("SWR_HOST_PROFILE") && atoi(getenv("SWR_HOST_PROFILE")) == 1;
     hipError_t e;
     if ((e = hipSetDevice(dev)) != hipSuccess || (e = prepare_device()) != hipSuccess ||
@@ -1148,11 +1317,12 @@ int create_single(int dev, swr_context** out) {
             else c->bin_stream_own = c->bin_stream;
             // SWR_HOST_THREADS=1: enqueue everything from the caller's thread (no helper)
             const char* ht = getenv("SWR_HOST_THREADS");
-            if (c->bin_stream_own && !(ht && ht[0] == '1')) { c->bin_worker = new Worker(); c->bin_worker->start(dev); }
+            if (ht && ht[0] == '1') helpers = 0;
             { const char* be = getenv("SWR_BIND_EVENTS"); c->bind_events = !(be && be[0] == '0'); }
             { const char* ii = getenv("SWR_INLINE_IDLE"); c->inline_idle = !(ii && ii[0] == '0'); }
-            const char* ew = getenv("SWR_EVENT_WAITS");
-            if (c->bin_worker && !(ew && ew[0] == '1')) { c->ras_worker = new Worker(); c->ras_worker->start(dev); }
+            const char* ew = getenv("SWR_EVENT_WAITS");     // =1: no raster helper; the caller's thread orders the streams by event waits
+            if (c->bin_stream_own && helpers >= 2) { c->bin_worker = new Worker(); c->bin_worker->start(dev, true); }
+            if (c->bin_stream_own && helpers >= 1 && !(ew && ew[0] == '1')) { c->ras_worker = new Worker(); c->ras_worker->start(dev, true); }
         }
         for (auto& sl : c->slot) {
             hipEventCreateWithFlags(&sl.bin_done, hipEventDisableTiming);
@@ -1246,15 +1416,17 @@ int swr_context_create(const swr_config* cfg, swr_context** out) {
     if (dev >= ndev) return fail(nullptr, SWR_ERR_BAD_ARG, "device %d out of range (%d devices)", dev, ndev);
     const uint32_t n = cfg ? cfg->device_count : 0;
     if (n > 64) return fail(nullptr, SWR_ERR_BAD_ARG, "device_count %u > 64", n);
-    if (n <= 1) return create_single(dev, out);
+    const uint32_t budget = cfg ? cfg->wait_budget_ms : 0u;
+    if (n <= 1) return create_single(dev, out, 2, budget);
     // group: sub-context k on device (dev + k) % min(n, visible devices) — with fewer GPUs than bands several bands
     // share a GPU (same code path; how a 1-GPU box tests the 8-band layout)
     swr_context* g = new swr_context();
     g->device = dev;
+    if (budget) g->wait_budget_ms = budget;
     const int span = std::min<int>((int)n, ndev);
     for (uint32_t k = 0; k < n; k++) {
         swr_context* kid = nullptr;
-        int rc = create_single((dev + (int)(k % (uint32_t)span)) % ndev, &kid);
+        int rc = create_single((dev + (int)(k % (uint32_t)span)) % ndev, &kid, 1, budget);
         if (rc) {
             for (swr_context* x : g->kids) destroy_single(x);
             delete g;
@@ -1296,6 +1468,7 @@ int swr_context_band_info(const swr_context* c, int32_t band, int32_t* device, i
 int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_count,
                      const int64_t* indices, int64_t index_count) {
     if (!c) return SWR_ERR_BAD_ARG;
+    c->scene_id = 0;      // the resident scene changes: a later swr_render must not take it for its own
     if (is_group(c))   // replicated: every device reads the caller's arrays itself, over its own PCIe link
         return group_run(c, [=](swr_context* k) { return single_scene_upload(k, vertices, vertex_count, indices, index_count); });
     return single_scene_upload(c, vertices, vertex_count, indices, index_count);
@@ -1303,6 +1476,7 @@ int swr_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_
 
 int swr_scene_attributes(swr_context* c, const swr_vertex_attr* attributes, int64_t vertex_count) {
     if (!c) return SWR_ERR_BAD_ARG;
+    c->scene_id = 0;      // the resident scene changes: a later swr_render must not take it for its own
     if (is_group(c)) return group_run(c, [=](swr_context* k) { return single_scene_attributes(k, attributes, vertex_count); });
     return single_scene_attributes(c, attributes, vertex_count);
 }
@@ -1319,6 +1493,7 @@ int swr_material_set(swr_context* c, const swr_material* m) {
 
 int swr_texture_upload(swr_context* c, const void* bgra8, int32_t width, int32_t height) {
     if (!c) return SWR_ERR_BAD_ARG;
+    c->scene_id = 0;      // the resident scene changes: a later swr_render must not take it for its own
     if (is_group(c)) return group_run(c, [=](swr_context* k) { return single_texture_upload(k, bgra8, width, height); });
     return single_texture_upload(c, bgra8, width, height);
 }
@@ -1517,18 +1692,64 @@ int swr_render(swr_context* c, const swr_render_pass* p) {
                     p->primitive_type == SWR_PRIMITIVE_LINE ? 2 : 3);
     if (!p->depth || (!(p->flags & SWR_FLAG_NO_COLOR) && !p->color))
         return fail(c, SWR_ERR_BAD_ARG, "swr_render: colour/depth image pointer is NULL");
+    using clk = std::chrono::steady_clock;
+    auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<float, std::milli>(b - a).count(); };
+    const auto t0 = clk::now();
     int rc;
-    if ((rc = swr_scene_upload(c, p->vertices, p->vertex_count, p->indices, p->index_count))) return rc;
+    // Scene identity: the caller's promise that the arrays hold what they held at the last call with this id — the
+    // resident copy (and the triangle stream built from it) is then used as it is, like the reference's GpuRenderer
+    // keeps its MTLBuffers across calls (GpuRenderer.swift:32-33,41-67) for the app's one mesh (App.swift:153-185).
+    const bool cached = p->scene_id != 0 && p->scene_id == c->scene_id && p->vertex_count == c->scene_nv &&
+                        p->index_count == c->scene_ni && (p->attributes != nullptr) == c->scene_attrs &&
+                        (p->texture == nullptr ? c->scene_tex == nullptr
+                                               : (c->scene_tex != nullptr && p->tex_width == c->scene_tw && p->tex_height == c->scene_th));
+    c->rt = swr_render_times{};
+    c->rt.scene_cached = cached ? 1 : 0;
+    if (!cached) {
+        c->scene_id = 0;
+        if ((rc = swr_scene_upload(c, p->vertices, p->vertex_count, p->indices, p->index_count))) return rc;
+        if (p->attributes && (rc = swr_scene_attributes(c, p->attributes, p->vertex_count))) return rc;
+        if (p->texture && (rc = swr_texture_upload(c, p->texture, p->tex_width, p->tex_height))) return rc;
+        c->scene_id = p->scene_id; c->scene_nv = p->vertex_count; c->scene_ni = p->index_count;
+        c->scene_attrs = p->attributes != nullptr;
+        c->scene_tex = p->texture; c->scene_tw = p->tex_width; c->scene_th = p->tex_height;
+        // the split inside the upload: HIP events of (the slowest band of) the upload itself
+        const swr_context* k0 = c->kids.empty() ? c : c->kids[0];
+        float h2d = k0->up_h2d_ms, build = k0->up_build_ms;
+        for (const swr_context* k : c->kids) { h2d = std::max(h2d, k->up_h2d_ms); build = std::max(build, k->up_build_ms); }
+        c->rt.h2d_ms = h2d;
+        c->rt.stream_build_ms = ms(t0, clk::now()) - h2d;       // index check, sort, gather, attribute / texture passes, allocation
+        (void)build;
+    }
+    const auto t1 = clk::now();
     // the pass carries its own fragment stage: NULL material = the reference's passthrough
     if ((rc = swr_material_set(c, p->material))) return rc;
-    if (p->attributes && (rc = swr_scene_attributes(c, p->attributes, p->vertex_count))) return rc;
-    if (p->texture && (rc = swr_texture_upload(c, p->texture, p->tex_width, p->tex_height))) return rc;
     if ((rc = swr_target_set(c, p->width, p->height, 0, p->height))) return rc;
     if ((rc = swr_draw_primitives(c, p->transform, p->flags, p->primitive_type))) return rc;
     // colour and depth leave every device together (two copy streams each); synchronous on return like
     // scheduleAndWait (Metal+Extensions.swift:57-67)
     if ((rc = swr_present(c, (p->flags & SWR_FLAG_NO_COLOR) ? nullptr : p->color, p->depth))) return rc;
-    return swr_present_wait(c);
+    if ((rc = swr_sync(c))) return rc;                           // (the frame itself; repairs an overflow before the copy is waited for)
+    const auto t2 = clk::now();
+    if ((rc = swr_present_wait(c))) return rc;
+    const auto t3 = clk::now();
+    c->rt.draw_ms = ms(t1, t2);
+    c->rt.gather_ms = ms(t2, t3);
+    c->rt.total_ms = ms(t0, t3);
+    return SWR_OK;
+}
+
+int swr_render_timings(swr_context* c, swr_render_times* out) {
+    if (!c || !out) return SWR_ERR_BAD_ARG;
+    *out = c->rt;
+    return SWR_OK;
+}
+
+int swr_debug_fault(swr_context* c, int fault) {
+    if (!c || fault < SWR_FAULT_NONE || fault > SWR_FAULT_ENQUEUE) return SWR_ERR_BAD_ARG;
+    if (is_group(c)) { for (swr_context* k : c->kids) k->inject.store(fault); return SWR_OK; }
+    c->inject.store(fault);
+    return SWR_OK;
 }
 
 }  // extern "C"

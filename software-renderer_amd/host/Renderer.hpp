@@ -142,15 +142,18 @@ class Context {
 public:
     // deviceCount > 1: one context drives that many tile-row bands, on as many GPUs as are visible (swr_config.device_count)
     explicit Context(uint32_t deviceCount = 0) {
-        swr_config cfg{deviceCount > 1 ? 0 : -1, deviceCount};
+        swr_config cfg{deviceCount > 1 ? 0 : -1, deviceCount, 0, 0};
         int rc = swr_context_create(&cfg, &ctx_);
         if (rc) throw RenderError(rc, swr_last_error(nullptr));
     }
     ~Context() { swr_context_destroy(ctx_); }
     Context(const Context&) = delete;
     Context& operator=(const Context&) = delete;
-    void render(const RenderPass& p, uint32_t flags) {
+    // sceneId != 0: the caller's promise that p.vertices / p.indices / p.attributes / the texture hold what they held at
+    // the last call with this id (swr_render_pass.scene_id): nothing is uploaded, the pass costs one resident frame + the gather
+    void render(const RenderPass& p, uint32_t flags, uint64_t sceneId = 0) {
         swr_render_pass rp{};
+        rp.scene_id = sceneId;
         rp.color = p.colorBuffer.pointer;
         rp.depth = p.depthBuffer.pointer;
         rp.width = p.colorBuffer.width;
@@ -197,7 +200,13 @@ private:
 // semantics exactly as written — painter's order, depth image left at +inf — executed on the GPU.
 class Renderer {
 public:
-    void render(const RenderPass& renderPass) { ctx_.render(renderPass, 0); }
+    // The reference's caller draws the same mesh every display frame with a new transform (App.swift:153-185).
+    // staticScene = true tells the renderer so: the mesh of the first render(renderPass:) stays resident on the GPU
+    // (what GpuRenderer.swift:32-33,41-67 does with its MTLBuffers) until sceneVersion is changed or the vertex / index
+    // counts differ.  false (the default) uploads on every call, whatever the arrays hold.
+    bool staticScene = false;
+    uint64_t sceneVersion = 1;          // bump after editing the arrays of a static scene in place
+    void render(const RenderPass& renderPass) { ctx_.render(renderPass, 0, staticScene ? sceneVersion : 0); }
 private:
     detail::Context ctx_;
 };
@@ -215,9 +224,13 @@ public:
     // true: the Metal kernels' own rules (round() snap, ROI threads + inside test, UNORM rounding,
     // ROI-min == 0 skip; Shaders.metal:57-167, GpuRenderer.swift:122-124) instead of the CPU renderer's
     bool metalRules = false;
+    // see Renderer::staticScene: the resident mesh of GpuRenderer.swift:32-33,41-67
+    bool staticScene = false;
+    uint64_t sceneVersion = 1;
     void render(const RenderPass& renderPass) {
         ctx_.render(renderPass, metalRules ? (uint32_t)SWR_FLAG_METAL_RULES
-                                           : (depthTest ? (uint32_t)SWR_FLAG_DEPTH_TEST : 0u));
+                                           : (depthTest ? (uint32_t)SWR_FLAG_DEPTH_TEST : 0u),
+                    staticScene ? sceneVersion : 0);
     }
 private:
     detail::Context ctx_;

@@ -19,11 +19,17 @@ final class GpuRenderer {
     var attributes: [swr_vertex_attr]? = nil
     var material: swr_material? = nil
     var texture: Image<Pixel>? = nil
+    /// The app draws the same mesh every display frame with a new transform (App.swift:153-185); the original keeps its
+    /// MTLBuffers across calls (GpuRenderer.swift:32-33,41-67).  staticScene = true: the mesh of the first
+    /// render(renderPass:) stays resident on the GPU until sceneVersion changes (or the counts differ) — the pass then
+    /// costs one resident frame plus the gather instead of a 120 MB upload.  false: upload on every call.
+    var staticScene = false
+    var sceneVersion: UInt64 = 1
 
     /// deviceCount > 1: ONE renderer drives that many GPUs — the framebuffer is cut into tile-row bands, every band is
     /// copied straight into its rows of the caller's image (swr_config.device_count; include/swr.h).
     init(deviceCount: UInt32 = 0) {
-        var cfg = swr_config(device: deviceCount > 1 ? 0 : -1, device_count: deviceCount)
+        var cfg = swr_config(device: deviceCount > 1 ? 0 : -1, device_count: deviceCount, wait_budget_ms: 0, reserved: 0)
         let rc = swr_context_create(&cfg, &ctx)
         precondition(rc == SWR_OK, String(cString: swr_last_error(nil)))   // original: try! (GpuRenderer.swift:20-31)
     }
@@ -40,6 +46,7 @@ final class GpuRenderer {
         pass.depth_bytes_per_row = Int64(renderPass.depthBuffer.bytesPerRow)
         pass.primitive_type = renderPass.primitiveType == .triangle ? 0 : (renderPass.primitiveType == .line ? 1 : 2)
         pass.flags = metalRules ? UInt32(SWR_FLAG_METAL_RULES) : (depthTest ? UInt32(SWR_FLAG_DEPTH_TEST) : 0)
+        pass.scene_id = staticScene ? sceneVersion : 0
         withUnsafeBytes(of: renderPass.transform) { src in          // matrix_float4x4 = 4 float4 columns
             withUnsafeMutableBytes(of: &pass.transform) { $0.copyMemory(from: src) }
         }

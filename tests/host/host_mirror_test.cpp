@@ -116,6 +116,34 @@ int main() {
         for (long i = 0; i < W * H; i++) pts += color[i].a == 255;
         CHECK(pts == 3);
         CHECK(pass.colorBuffer.at(128, 64).r == 255);   // vertex (0, .5) -> (128, 64)
+
+        // The app's frame loop (App.swift:153-185): the same mesh every frame, a new transform.  staticScene keeps the mesh
+        // resident (GpuRenderer.swift:32-33,41-67); editing the arrays WITHOUT telling the renderer keeps the old mesh,
+        // staticScene = false (scene_id 0) or a new sceneVersion picks the edit up.
+        pass.primitiveType = PrimitiveType::triangle;
+        pass.vertices = {Vertex(0, .8f, .2f, 1, 0, 0), Vertex(.8f, -.8f, .2f, 1, 0, 0), Vertex(-.8f, -.8f, .2f, 1, 0, 0)};
+        pass.indices = {0, 1, 2};
+        gpuRenderer.staticScene = true;
+        for (int frame = 0; frame < 3; frame++) {
+            pass.transform = matrix_float4x4::identity();
+            pass.transform.columns[3][0] = 0.1f * (float)frame;         // slide to the right
+            gpuRenderer.render(pass);
+            CHECK(pass.colorBuffer.at(128 + (int)(12.8f * (float)frame), 128).r == 255);
+        }
+        pass.transform = matrix_float4x4::identity();
+        pass.vertices[0] = Vertex(0, .8f, .2f, 0, 1, 0);               // recolour a corner in place ...
+        pass.vertices[1] = Vertex(.8f, -.8f, .2f, 0, 1, 0);
+        pass.vertices[2] = Vertex(-.8f, -.8f, .2f, 0, 1, 0);
+        gpuRenderer.render(pass);                                        // ... same sceneVersion: the resident (red) mesh is drawn
+        CHECK(pass.colorBuffer.at(128, 128).r == 255 && pass.colorBuffer.at(128, 128).g == 0);
+        gpuRenderer.sceneVersion++;                                      // tell the renderer: uploaded again
+        gpuRenderer.render(pass);
+        CHECK(pass.colorBuffer.at(128, 128).g == 255 && pass.colorBuffer.at(128, 128).r == 0);
+        pass.vertices[0] = Vertex(0, .8f, .2f, 0, 0, 1); pass.vertices[1] = Vertex(.8f, -.8f, .2f, 0, 0, 1);
+        pass.vertices[2] = Vertex(-.8f, -.8f, .2f, 0, 0, 1);
+        gpuRenderer.staticScene = false;                                 // scene_id 0: every call uploads (the default)
+        gpuRenderer.render(pass);
+        CHECK(pass.colorBuffer.at(128, 128).b == 255 && pass.colorBuffer.at(128, 128).g == 0);
     } catch (const RenderError& e) {
         std::printf("RenderError %d: %s\n", e.code, e.what());
         return 2;

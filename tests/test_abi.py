@@ -48,11 +48,13 @@ def test_product_does_not_link_the_oracle(swr):
 def test_struct_layouts_match_the_swift_types(swr):
     """Vertex = 2 x SIMD3<Float> padded to 16 B (Renderer.swift:154-157); RenderPass fields."""
     B = swr.binding
-    assert ctypes.sizeof(B.RenderPass) == 8 * 10 + 4 + 4 + 64 + 3 * 8 + 2 * 4
+    assert ctypes.sizeof(B.RenderPass) == 8 * 10 + 4 + 4 + 64 + 3 * 8 + 2 * 4 + 8 == 192
     assert B.RenderPass.transform.offset == 88
     assert B.RenderPass.attributes.offset == 152          # extended fragment stage (ABI 2)
+    assert B.RenderPass.scene_id.offset == 184            # scene identity (ABI 4)
     assert ctypes.sizeof(B.Material) == 56
-    assert ctypes.sizeof(B.Config) == 8 and B.Config.device_count.offset == 4   # swr_config (ABI 3: device_count)
+    assert ctypes.sizeof(B.Config) == 16 and B.Config.device_count.offset == 4 and B.Config.wait_budget_ms.offset == 8   # swr_config (ABI 4)
+    assert ctypes.sizeof(B.RenderTimes) == 28
     assert ctypes.sizeof(B.Timings) == 5 * 4 + 4 + 3 * 8
 
 

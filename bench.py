@@ -235,14 +235,25 @@ def main():
         "avg_launch_ms": round(raster_ms, 5), "launches_timed": frames, "timed_every_nth_launch": SAMPLE,
         "ms_per_step_while_sampling": round(dt_s / roof_steps * 1e3, 4),
         "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 5),
+        # the contract's `bound` names the roofline the fraction is quoted against (the HBM-write roofline of north_star);
+        # what the kernel is actually limited by is VALU issue: see .valu
+        "binding_resource": "valu_issue",
     }
+    # the whole frame against its compulsory HBM bytes (SURVEY 8(d) secondary: framebuffer written once + the scene read once)
+    compulsory = W * (r1 - r0) * bytes_per_px + 32 * scene.vertices.shape[0] + 8 * scene.indices.size
+    roofline["frame"] = {"bytes": compulsory, "achieved": round(compulsory / (ms_per_step * 1e-3) / 1e9, 2), "unit": "GB/s",
+                         "frac": round(compulsory / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                         "note": "compulsory bytes of one frame / ms_per_step of the headline pass"}
     if n_gpus == 1 and valu.get("k_raster_valu_wave_insts_per_launch") and raster_ms > 0:
         insts = float(valu["k_raster_valu_wave_insts_per_launch"])
         roofline["valu"] = {
             "insts": insts, "source": valu.get("source", "profiles/valu.json"),
             "peak_wave_insts_per_s": VALU_PEAK_WAVE_INSTS_PER_S,
             "frac": round(insts / (raster_ms * 1e-3) / VALU_PEAK_WAVE_INSTS_PER_S, 4),
-            "note": "the kernel is VALU-issue / latency bound, not HBM bound: this is the fraction of the binding resource"}
+            "measured_on": valu.get("commit"),
+            "note": "the kernel is VALU-issue bound, not HBM bound: this is the fraction of the binding resource.  insts is a "
+                    "static count (SQ_INSTS_VALU of one launch, rocprofv3 pass with frame pipelining off, profiles/); the duration "
+                    "it is divided by is this run's pipelined launch average"}
 
     extra = {"frames_per_s": round(args.steps / dt, 2), "band_rows": [r0, r1], "tile": list(swr_amd.tile_shape()),
              "bands": [{"device": d, "rows": [a, b]} for d, a, b in bands],
@@ -310,16 +321,29 @@ def main():
             if rank == 0:
                 os.remove(shm_path)
         else:
-            # the full drop-in call: host pointers in (pageable scene arrays, page-locked images), pixels out
-            rts = []
-            for _ in range(3):
-                t0 = time.perf_counter()
-                ctx.render(scene.vertices, scene.indices, scene.transform, W, H, flags,
-                           color=None if color_img is None else color_img.array, depth=depth_host.array)
-                rts.append(time.perf_counter() - t0)
-            extra["swr_render_ms"] = round(float(np.median(rts)) * 1e3, 3)
-            extra["swr_render_note"] = ("one synchronous swr_render: H2D of 120 MB scene + Morton sort / stream build + draw + "
-                                        "gather into page-locked images; median of 3")
+            # the full drop-in call, as the reference's caller makes it (App.swift:153-185: the same mesh every frame, a new
+            # transform): host pointers in (pageable scene arrays, page-locked images), pixels out.  cold = scene_id 0 (upload
+            # every call, ABI 3's only behaviour); cached = the same non-zero scene_id again (resident mesh: one frame + gather)
+            def render_calls(scene_id, n):
+                rows = []
+                for _ in range(n):
+                    t0 = time.perf_counter()
+                    ctx.render(scene.vertices, scene.indices, scene.transform, W, H, flags,
+                               color=None if color_img is None else color_img.array, depth=depth_host.array, scene_id=scene_id)
+                    wall = (time.perf_counter() - t0) * 1e3
+                    rows.append(dict(ctx.render_timings(), wall_ms=wall))
+                med = {k: round(float(np.median([r[k] for r in rows])), 3) for k in rows[0]}
+                med["scene_cached"] = int(med["scene_cached"])
+                return med
+            cold = render_calls(0, 3)
+            render_calls(0x5CE4E, 1)                    # makes the mesh resident under an id
+            cached = render_calls(0x5CE4E, 5)
+            extra["swr_render_ms"] = cold["wall_ms"]
+            extra["swr_render"] = {"cold": cold, "cached_scene": cached,
+                                   "note": "one synchronous swr_render (medians).  cold: scene_id 0 = H2D of the 120 MB scene from pageable "
+                                           "arrays + index check / Morton sort / stream build + one frame + gather into page-locked images.  "
+                                           "cached_scene: the same non-zero swr_render_pass.scene_id again = one resident frame + the gather "
+                                           "(PCIe-bound).  h2d_ms from HIP events, the rest host wall clock"}
             depth_host.free()
             if color_img is not None:
                 color_img.free()
@@ -329,6 +353,10 @@ def main():
         "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "value_host_visible": (extra.get("host_visible") or {}).get("Mpixels_per_s"),
+        "value_note": "value = device-resident frames (inputs and framebuffer in HBM, as the bench contract asks); value_host_visible = "
+                      "the same frames with every band copied into one page-locked host image (SURVEY 8(d): 'host-visible image complete'), "
+                      "PCIe-bound per GPU",
         "latency_ms": round(latency_ms, 4),
         "latency_note": "ms_per_step is inverse throughput with up to three frames in flight (binning of frames N+1, N+2 beside "
                         "the raster of frame N); latency_ms is one frame alone, swr_draw -> swr_sync",

@@ -153,10 +153,14 @@ def load_library():
     L.swr_host_free.restype = None
     L.swr_host_register.argtypes = [vp, ctypes.c_size_t]
     L.swr_host_unregister.argtypes = [vp]
-    L.swr_render_timings.argtypes = [vp, ctypes.POINTER(RenderTimes)]
-    L.swr_render_timings.restype = ctypes.c_int
-    L.swr_debug_fault.argtypes = [vp, ctypes.c_int]
-    L.swr_debug_fault.restype = ctypes.c_int
+    try:
+        L.swr_render_timings.argtypes = [vp, ctypes.POINTER(RenderTimes)]
+        L.swr_render_timings.restype = ctypes.c_int
+        L.swr_debug_fault.argtypes = [vp, ctypes.c_int]
+        L.swr_debug_fault.restype = ctypes.c_int
+    except AttributeError:
+        if not os.environ.get("SWR_LIBRARY"):      # only an older A/B build loaded by tools/ may lack the ABI 4 entry points
+            raise
     L.swr_present.argtypes = [vp, vp, vp]
     L.swr_present_wait.argtypes = [vp]
     for name in ("swr_context_bands", "swr_context_band_info", "swr_host_register", "swr_host_unregister", "swr_present",

@@ -641,16 +641,22 @@ int enqueue_frame(swr_context* c) {
     // one box (tools/ab_sort_stream.py, tools/bt_bands.sh; untimed frames of cfg4, us per frame):
     //   whole 4K frame (4 080 tiles): 112 vs 122 -> binning stream;  half / quarter / eighth bands: 83 / 59 / 41
     //   vs 73 / 49 / 40 -> raster stream;  light frames (cfg2, 6 k triangles): 37 vs 43 -> binning stream.
-    // SWR_SORT_STREAM=0/1 forces either.
-    static const int sort_stream_mode = getenv("SWR_SORT_STREAM") ? atoi(getenv("SWR_SORT_STREAM")) : -1;
+    // -DSWR_TUNE_SORT_STREAM=0/1 forces either.
+#ifndef SWR_TUNE_SORT_STREAM
+#define SWR_TUNE_SORT_STREAM (-1)     // 0 / 1: k_sort_bins always on the binning / raster stream (tuning builds)
+#endif
+#ifndef SWR_TUNE_SORT_SPARSE
+#define SWR_TUNE_SORT_SPARSE 0        // 1: launch k_sort_bins on sparse frames too
+#endif
+    constexpr int sort_stream_mode = SWR_TUNE_SORT_STREAM;
     const bool sort_on_raster_stream = sort_stream_mode >= 0 ? sort_stream_mode == 1
                                                             : (sb != sr && f.ntri >= 200000 && tiles_of(c->tg) < 3000);
     // Sparse frames need no k_sort_bins: when the fullest bin of the latest binned frame (a pinned word k_fill_lds
     // overwrites every frame; 0xFFFFFFFF after a new scene or target) fits two chunks, every tile of THIS frame is
     // expected to be walked by all four waves together (row-split mode), where the order inside the bin does not
     // matter — k_raster masks the class tags itself.  A wrong guess costs time, never pixels.  (cfg5: 0.321 -> 0.313 ms,
-    // the app's sphere 18.6 -> 17.1 us; SWR_SORT_SPARSE=1 sorts always.)
-    static const bool sort_sparse = getenv("SWR_SORT_SPARSE") && getenv("SWR_SORT_SPARSE")[0] == '1';
+    // the app's sphere 18.6 -> 17.1 us; -DSWR_TUNE_SORT_SPARSE=1 sorts always.)
+    constexpr bool sort_sparse = SWR_TUNE_SORT_SPARSE != 0;
     if (!sort_sparse && sort_stream_mode < 0 && c->h_pairs[swr_context::PAIR_RING] <= 128u) f.skip_sort = 1;
     const bool all = c->timing >= 2;
     if (f.ntri <= 0) { int rc = sync_streams(c); if (rc) return rc; pair_word(c, frame) = 0; }

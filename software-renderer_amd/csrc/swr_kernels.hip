@@ -442,7 +442,17 @@ __device__ __forceinline__ int wave_incl_add(int v);
 // raster workgroups, so the binning of frame N+1 really runs WHILE frame N is rasterised; a 1024-thread one
 // (the former default, SWR_BIN_BT=1024) needs four free wave slots and 208 VGPRs per SIMD at once and only gets
 // onto a CU in the raster's tail (cfg4: 132 -> 112 us per frame, tools/bt_g_sweep.sh).
-constexpr int BIN_THREADS = 1024;  // workgroup size of k_setup_hist / k_fill_lds (512 measured no better beside raster workgroups)
+// Tuning constants that used to be environment variables (rounds 1-2 swept them): compile-time now, so a stray variable
+// cannot change how the product schedules.  A sweep builds side libraries: make ab NAME=g512 ABFLAGS=-DSWR_TUNE_BIN_G=512.
+#ifndef SWR_TUNE_BIN_G
+#define SWR_TUNE_BIN_G 256          // binning workgroups (256 threads each): one per CU
+#endif
+#ifndef SWR_TUNE_HIST16
+#define SWR_TUNE_HIST16 1           // packed 16-bit LDS counters in k_setup_hist
+#endif
+#ifndef SWR_TUNE_VSPLIT
+#define SWR_TUNE_VSPLIT (-1)        // log2 of the k_raster workgroups per tile; -1 = 4 per tile on grids of <= 320 tiles, else 1
+#endif
 
 // ---- binning, LDS path (default): no global atomics ------------------------------------------
 // Can the 64 primitives of stream group `g` be skipped by this band?  True only when the projection of
@@ -1534,9 +1544,18 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                 if (ZTEST) { ta = tabA[wbase + owner]; tb = tabB[wbase + owner]; }
                 const int cp = __float_as_int(tb.w);
                 const int dyi = yl - (cp >> 16);                                 // y - C.y
+                // Wide visits (screen-filling triangles: the lanes of a step sit in the same row and the same 32 pixels) walk
+                // their groups in a lane-rotated order, so that one ds_min_u64 instruction meets eight addresses eight times
+                // instead of one address 64 times: LDS atomics on one address serialise (profiles/r03/wide_rotation_ab.txt).
+#ifndef SWR_WIDE_ROT
+#define SWR_WIDE_ROT 1
+#endif
+                const bool rotated = SWR_WIDE_ROT && SL > 0 && __any(nvalid0 > UNIT);           // more than one group somewhere (wave-uniform)
+                const int rot = rotated ? (lane & ((1 << SL) - 1)) : 0;
 #pragma unroll 1
-                for (int sg = 0; sg < (1 << SL); sg++) {                         // the visit's groups of four pixels (one: SL == 0)
-                    if (SL > 0 && !__any(nvalid0 > UNIT * sg)) break;           // wave-uniform
+                for (int sg0 = 0; sg0 < (1 << SL); sg0++) {                      // the visit's groups of four pixels (one: SL == 0)
+                    if (SL > 0 && !rotated && (SWR_WIDE_ROT ? sg0 > 0 : !__any(nvalid0 > UNIT * sg0))) break;   // wave-uniform
+                    const int sg = SL > 0 ? ((sg0 + rot) & ((1 << SL) - 1)) : 0;
                     const int xl0 = xl00 + UNIT * sg, lidx0 = lidx00 + UNIT * sg;
                     const int nvalid = min(max(nvalid0 - UNIT * sg, 0), UNIT);
                     const int dxi = xl0 - (int)(short)(cp & 0xFFFF);             // x - C.x of the group's first pixel
@@ -1933,11 +1952,9 @@ BinPlan plan_binning(int64_t ntri, int ntiles) {
     p.lds_bytes = (size_t)ntiles * 4;
     const char* force = getenv("SWR_BIN_MODE");
     p.use_lds = p.lds_bytes <= 136 * 1024 && !(force && force[0] == 'a');   // 'atomic' forces the fallback (LDS also holds a workgroup's group list)
-    static const int bt = getenv("SWR_BIN_BT") ? atoi(getenv("SWR_BIN_BT")) : 256;
-    p.threads = bt == BIN_THREADS ? BIN_THREADS : 256;
+    p.threads = 256;
     int64_t g = (ntri + p.threads - 1) / p.threads;
-    static const int gmax = getenv("SWR_BIN_G") ? atoi(getenv("SWR_BIN_G")) : 256;   // 1 per CU (measured best)
-    if (g > gmax) g = gmax;
+    if (g > SWR_TUNE_BIN_G) g = SWR_TUNE_BIN_G;   // 1 per CU (measured best)
     if (g > MAX_BIN_G) g = MAX_BIN_G;
     if (g < 1) g = 1;
     p.G = (int)g;
@@ -1957,9 +1974,6 @@ void launch_texture_to_float(const uint32_t* bgra, int64_t n, float4* out, hipSt
 // (per loaded code object): swr_context_create calls this after hipSetDevice for every device it opens.
 hipError_t prepare_device() {
     hipError_t e;
-    if ((e = hipFuncSetAttribute((const void*)k_setup_hist<BIN_THREADS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_setup_hist<BIN_THREADS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_fill_lds<BIN_THREADS>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_bin<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
@@ -1978,10 +1992,7 @@ hipError_t prepare_device() {
 // (k_fill_lds with 16-bit running counts in LDS and its bin positions gathered from its row of M was built too: alone
 // 23.2 -> 33.9 us, and with BOTH walks co-resident with the raster the frame went 0.096 -> 0.111 ms although k_raster
 // itself got faster, 97 -> 93 us: profiles/r02/hist16_ab.txt.  Only k_setup_hist keeps the small histogram.)
-static bool bin_h16(int per) {
-    static const bool on = !(getenv("SWR_HIST16") && getenv("SWR_HIST16")[0] == '0');
-    return on && (int64_t)per * 64 < 65536;
-}
+static bool bin_h16(int per) { return SWR_TUNE_HIST16 && (int64_t)per * 64 < 65536; }
 
 void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
     if (f.ntri <= 0) return;
@@ -1991,13 +2002,8 @@ void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
         const int per = live_groups_per_workgroup(f.ntri, f.plan.G);
         const bool h16 = bin_h16(per);
         const size_t lds = (h16 ? (size_t)((ntiles + 1) / 2) * 4 : f.plan.lds_bytes) + (size_t)(per + 1) * 4;
-        if (f.plan.threads == 256) {
-            if (h16) hipLaunchKernelGGL((k_setup_hist<256, true>), dim3(f.plan.G), dim3(256), lds, s, a, f.bin_matrix, f.live, per, ntiles);
-            else hipLaunchKernelGGL((k_setup_hist<256, false>), dim3(f.plan.G), dim3(256), lds, s, a, f.bin_matrix, f.live, per, ntiles);
-        } else {
-            if (h16) hipLaunchKernelGGL((k_setup_hist<BIN_THREADS, true>), dim3(f.plan.G), dim3(BIN_THREADS), lds, s, a, f.bin_matrix, f.live, per, ntiles);
-            else hipLaunchKernelGGL((k_setup_hist<BIN_THREADS, false>), dim3(f.plan.G), dim3(BIN_THREADS), lds, s, a, f.bin_matrix, f.live, per, ntiles);
-        }
+        if (h16) hipLaunchKernelGGL((k_setup_hist<256, true>), dim3(f.plan.G), dim3(256), lds, s, a, f.bin_matrix, f.live, per, ntiles);
+        else hipLaunchKernelGGL((k_setup_hist<256, false>), dim3(f.plan.G), dim3(256), lds, s, a, f.bin_matrix, f.live, per, ntiles);
         hipLaunchKernelGGL(k_colscan, dim3((ntiles + 15) / 16), dim3(256), 0, s, f.bin_matrix, f.plan.G, ntiles,
                            f.tile_count);
     } else {
@@ -2046,14 +2052,9 @@ bool launch_fill(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     if (f.plan.use_lds) {
         const int per = live_groups_per_workgroup(f.ntri, f.plan.G);
         const int tagged = f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0;
-        if (f.plan.threads == 256)
-            SWR_LAUNCH(stop, k_fill_lds<256>, dim3(f.plan.G), dim3(256), (uint32_t)(f.plan.lds_bytes + 4 * 256), s,
-                       (const uint2*)f.ranges, f.ntri, (const uint32_t*)f.bin_matrix, (const uint32_t*)f.tile_count, f.tile_start,
-                       f.counters, f.host_counters, f.bins, f.capacity, (const uint32_t*)f.live, per, ntiles, (int)f.tg.tiles_x, tagged, f.host_max);
-        else
-            SWR_LAUNCH(stop, k_fill_lds<BIN_THREADS>, dim3(f.plan.G), dim3(BIN_THREADS), (uint32_t)(f.plan.lds_bytes + 4 * BIN_THREADS), s,
-                       (const uint2*)f.ranges, f.ntri, (const uint32_t*)f.bin_matrix, (const uint32_t*)f.tile_count, f.tile_start,
-                       f.counters, f.host_counters, f.bins, f.capacity, (const uint32_t*)f.live, per, ntiles, (int)f.tg.tiles_x, tagged, f.host_max);
+        SWR_LAUNCH(stop, k_fill_lds<256>, dim3(f.plan.G), dim3(256), (uint32_t)(f.plan.lds_bytes + 4 * 256), s,
+                   (const uint2*)f.ranges, f.ntri, (const uint32_t*)f.bin_matrix, (const uint32_t*)f.tile_count, f.tile_start,
+                   f.counters, f.host_counters, f.bins, f.capacity, (const uint32_t*)f.live, per, ntiles, (int)f.tg.tiles_x, tagged, f.host_max);
     } else {
         const unsigned blocks = (unsigned)((f.ntri + 255) / 256);
         hipLaunchKernelGGL(k_fill, dim3(blocks), dim3(256), 0, s, f.ranges, f.ntri, f.tile_cursor, f.counters,
@@ -2097,8 +2098,8 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     // four times, the row steps and the pixel work are divided (the app's sphere: k_raster 19.9 -> 12.8 us, Metal rules
     // 25.6 -> 14.3 us).  Two per tile for 320-640 tiles (1/8 band of cfg4: 510 dense tiles) measured no gain (23.3 vs
     // 24.6 us): those workgroups are bound by the gather -> setup latency chain of their chunks, not by their rows
-    // (profiles/r02/vsplit_ab.txt).  SWR_VSPLIT=0/1/2 forces the log2 of the split.
-    static const int vs_mode = getenv("SWR_VSPLIT") ? atoi(getenv("SWR_VSPLIT")) : -1;
+    // (profiles/r02/vsplit_ab.txt).  -DSWR_TUNE_VSPLIT=0/1/2 forces the log2 of the split.
+    constexpr int vs_mode = SWR_TUNE_VSPLIT;
     a.vs_log = vs_mode >= 0 ? std::min(vs_mode, 2) : (ntiles * 4 <= 1280 ? 2 : 0);
     const unsigned tiles = ntiles << a.vs_log;
     const bool ext = f.material.shader != SWR_SHADER_PASSTHROUGH && a.color != nullptr;

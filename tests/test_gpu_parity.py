@@ -614,9 +614,9 @@ def test_stream_order_is_invisible_with_ties_and_nonfinite_vertices(gpu_ctx, ora
 
 
 @pytest.mark.parametrize("env", [{"SWR_SORT": "-1"}, {"SWR_SORT": "0", "SWR_CULL": "2"}, {"SWR_CULL": "0"},
-                                 {"SWR_BIN_BT": "1024", "SWR_SORT_STREAM": "1"}, {"SWR_SORT_STREAM": "0", "SWR_PIPELINE": "0"}],
+                                 {"SWR_BIN_MODE": "exact", "SWR_SORT": "-1"}, {"SWR_BIN_MODE": "exact", "SWR_PIPELINE": "0"}],
                          ids=["no-reorder(>=2^24 path)", "index-order+forced-cull", "no-cull",
-                              "1024-thread-binning+sort-on-raster-stream", "sort-on-binning-stream+no-pipelining"])
+                              "exact-bins+no-reorder", "exact-bins+no-pipelining"])
 def test_stream_modes_in_a_child_process(env):
     """The library reads SWR_SORT / SWR_CULL once: exercise the other modes in a child process.  SWR_SORT=-1 is the
     path scenes of 2^24 primitives or more take (slot == index, nothing in GeomRec.flags); SWR_CULL=2 runs the cull

@@ -1295,8 +1295,9 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             const int4 q0 = q0_pre;
             const float4 q1 = q1_pre;
             if (METAL) {
-                // TriState re-used: t00..t11 = A0,B0,A1,B1 of the `divider` formula, cf.y = p3.y, cx = p3.x,
-                // ch.s0 / ch.s2 = ROI min / max corner
+                // TriState re-used: t00..t11 = A0,B0,A1,B1 of the `divider` formula, cf.y = p3.y, cx = p3.x;
+                // ch.s0..s2 = the snapped vertices in y order (the order bits of the record: a stable sort of the snapped
+                // y's), for the row walk of the dense phase; the ROI's x-range is [minx, maxx]
                 int vx[3], vy[3];
                 decode_vertices(a.geo_full, prim, q0, q1, vx, vy);
                 MetalTri mt;
@@ -1305,18 +1306,24 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                 t.za = mt.z0; t.zb = mt.z1; t.zc = mt.z2;
                 t.cfx = mt.p3x; t.cfy = mt.p3y; t.cx = vx[2]; t.cy = vy[2];
                 t.prim = prim;
-                t.ch.small = (__float_as_uint(q1.w) & GEOM_SMALL) != 0;
+                const uint32_t fl = __float_as_uint(q1.w);
+                t.ch.small = (fl & GEOM_SMALL) != 0;
+                const int o0 = (fl >> GEOM_ORD_SHIFT) & 3, o1 = (fl >> (GEOM_ORD_SHIFT + 2)) & 3, o2 = (fl >> (GEOM_ORD_SHIFT + 4)) & 3;
+                auto pick = [](int o, int a0, int b0, int c0) { return o == 0 ? a0 : (o == 1 ? b0 : c0); };
+                t.ch.s0x = pick(o0, vx[0], vx[1], vx[2]); t.ch.s0y = pick(o0, vy[0], vy[1], vy[2]);
+                t.ch.s1x = pick(o1, vx[0], vx[1], vx[2]); t.ch.s1y = pick(o1, vy[0], vy[1], vy[2]);
+                t.ch.s2x = pick(o2, vx[0], vx[1], vx[2]); t.ch.s2y = pick(o2, vy[0], vy[1], vy[2]);
+                t.ch.r01 = t.ch.r12 = t.ch.r02 = 0.0f;
                 minx = min(vx[0], min(vx[1], vx[2])); maxx = max(vx[0], max(vx[1], vx[2]));
-                t.ch.s0x = minx; t.ch.s2x = maxx;
-                t.ch.s0y = min(vy[0], min(vy[1], vy[2])); t.ch.s2y = max(vy[0], max(vy[1], vy[2]));
-                t.ch.s1x = t.ch.s1y = 0; t.ch.r01 = t.ch.r12 = t.ch.r02 = 0.0f;
             } else {
                 load_tri(a.geo_full, prim, q0, q1, t, minx, maxx);
             }
             // visibility keys order by the ORIGINAL primitive index (Renderer.swift:222,258)
             if (a.reordered) t.prim = __float_as_uint(q1.w) >> GEOM_ORIG_SHIFT;
             ya = max(t.ch.s0y, Yw0);
-            yb = min(t.ch.s2y, Yw1);
+            // Metal rules: the samples of the ROI's last row lie at max-y + 0.5, half a pixel below every vertex: never
+            // inside (the float evaluation of :144-153 errs by ~2^-8 px at most for GEOM_SMALL extents), so it is not walked
+            yb = min(METAL ? t.ch.s2y - 1 : t.ch.s2y, Yw1);
             bxa = max(minx, X0);
             bxb = min(maxx, X1);
             // the dense path below needs the exact small-coordinate arithmetic; everything else
@@ -1378,7 +1385,7 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                 mt.p3x = bcast_f(t.cfx, src); mt.p3y = bcast_f(t.cfy, src);
                 mt.divider = mt.B1 * mt.A0 - mt.B0 * mt.A1;      // == (p1-p3)x(p2-p3): same products, same rounding
                 const uint32_t uprim = (uint32_t)bcast_i((int)t.prim, src);
-                const int xa = max(bcast_i(t.ch.s0x, src), X0), xb = min(bcast_i(t.ch.s2x, src), X1);
+                const int xa = bcast_i(bxa, src), xb = bcast_i(bxb, src);              // ROI x-range ∩ tile
                 const int uya = bcast_i(ya, src), uyb = bcast_i(yb, src);
                 if (xa > xb) continue;
                 const int w = xb - xa + 1;
@@ -1508,10 +1515,12 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             // starts (and stays) at S2.x.
             EdgeStep eL = {0, 0, 0, 0, 0, 1}, eK = eL, eR = eL;
             const int s1y = t.ch.s1y;
-            if (!METAL && mine) {
+            // Metal rules: the same two chains bound the pixels that can pass the inside test of a row (below); the chain
+            // there is the geometric one, so [S1,S2] starts at S1.x also when S1.y == S2.y.
+            if (mine) {
                 float rc0, rc1, rcr;
                 EdgeStep e0;
-                const int k1x = t.ch.s1y == t.ch.s2y ? t.ch.s2x : t.ch.s1x;
+                const int k1x = (!METAL && t.ch.s1y == t.ch.s2y) ? t.ch.s2x : t.ch.s1x;
                 edge_consts(t.ch.s0x, t.ch.s0y, t.ch.s1x, t.ch.s1y, e0, rc0);
                 edge_consts(k1x, t.ch.s1y, t.ch.s2x, t.ch.s2y, eK, rc1);
                 edge_consts(t.ch.s0x, t.ch.s0y, t.ch.s2x, t.ch.s2y, eR, rcr);
@@ -1640,7 +1649,21 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                 while (VAR != 4 && VAR != 10 && qcount < 64u && am != 0ull) {
                     int lo, hi;
                     if (METAL) {
-                        lo = max(t.ch.s0x, X0); hi = min(t.ch.s2x, X1);      // every ROI row spans the ROI's x-range
+                        // Shaders.metal:133-153 tests every pixel of the ROI row; only those between the two chains can pass.
+                        // The samples of row y lie at y + 0.5, strictly between the integer rows y and y + 1, where each
+                        // chain is ONE straight segment (vertices are integers).  Its truncated integer interpolant X(.)
+                        // (the stepper) is within one pixel of the chain at y and at y + 1, the chain at y + 0.5 lies between
+                        // the two, so a pixel whose centre x + 0.5 is inside has  min X - 1 <= x <= max X  over the four
+                        // values; a pixel outside that range is at least half a pixel outside the triangle, far more than
+                        // the float evaluation of the weights can err (~2^-8 px for extents below 2^15).
+                        const int L0 = eL.X, R0 = eR.X;
+                        EdgeStep nL = eL, nR = eR;
+                        edge_next_row(nL);
+                        edge_next_row(nR);
+                        if (y + 1 == s1y) nL = eK;
+                        lo = max(min(min(L0, nL.X), min(R0, nR.X)) - 1, bxa);
+                        hi = min(max(max(L0, nL.X), max(R0, nR.X)), bxb);
+                        if (__builtin_amdgcn_inverse_ballot_w64(am)) { eL = nL; eR = nR; }
                     } else {
                         lo = max(min(eL.X, eR.X), X0);                       // :278-280 swap, then the tile's scissor
                         hi = min(max(eL.X, eR.X), X1);

@@ -657,7 +657,8 @@ int enqueue_frame(swr_context* c) {
     // matter — k_raster masks the class tags itself.  A wrong guess costs time, never pixels.  (cfg5: 0.321 -> 0.313 ms,
     // the app's sphere 18.6 -> 17.1 us; -DSWR_TUNE_SORT_SPARSE=1 sorts always.)
     constexpr bool sort_sparse = SWR_TUNE_SORT_SPARSE != 0;
-    if (!sort_sparse && sort_stream_mode < 0 && c->h_pairs[swr_context::PAIR_RING] <= 128u) f.skip_sort = 1;
+    // (a word the GPU overwrites while frames are in flight: read it as what it is, a relaxed atomic)
+    if (!sort_sparse && sort_stream_mode < 0 && __atomic_load_n(&c->h_pairs[swr_context::PAIR_RING], __ATOMIC_RELAXED) <= 128u) f.skip_sort = 1;
     const bool all = c->timing >= 2;
     if (f.ntri <= 0) { int rc = sync_streams(c); if (rc) return rc; pair_word(c, frame) = 0; }
     if (!f.fixed_bins) fill_word(c, frame) = 0;
@@ -845,7 +846,7 @@ int ensure_stage(swr_context* c, int img) {
 // [row_begin, row_end) of the caller's full-size host image, on the image's own copy stream, behind frame_done[fb].
 // Page-locked destination: ONE hipMemcpyAsync straight into the caller's rows (returns at once).  Pageable
 // destination: pipelined through two pinned 8 MiB chunks (D2H of chunk k+1 overlaps the memcpy of chunk k; blocks).
-int copy_band(swr_context* c, int fb, int img, void* dst_full) {
+int copy_band(swr_context* c, int fb, int img, void* dst_full, uint64_t frame) {
     const size_t row = (size_t)c->tg.width * 4;
     const size_t bytes = (size_t)(c->tg.row_end - c->tg.row_begin) * row;
     if (!bytes) return SWR_OK;
@@ -868,7 +869,7 @@ int copy_band(swr_context* c, int fb, int img, void* dst_full) {
             }
             if (k > 0) {
                 const size_t j = k - 1, len = std::min(CH, bytes - j * CH);
-                { const int rcw = poll_event(c, c->stage_ev[img][j & 1], "a staged copy to the host", c->frame_no); if (rcw) return rcw; }
+                { const int rcw = poll_event(c, c->stage_ev[img][j & 1], "a staged copy to the host", frame); if (rcw) return rcw; }
                 memcpy(dst + j * CH, c->stage[img][j & 1], len);
             }
         }
@@ -1095,11 +1096,12 @@ int enqueue_present(swr_context* c, void* color_full, float* depth_full) {
     const int fb = c->fb_last;
     if (tiles_of(c->tg) == 0) return SWR_OK;
     const bool want_color = color_full && !(c->last_flags & SWR_FLAG_NO_COLOR);
-    auto copies = [c, fb, want_color, color_full, depth_full]() -> int {
+    const uint64_t frame = c->frame_no ? c->frame_no - 1 : 0;      // the frame being presented (for messages)
+    auto copies = [c, fb, want_color, color_full, depth_full, frame]() -> int {
         int rc;
         HIP_TRY(c, hipEventRecord(c->frame_done[fb], c->stream));
-        if (want_color && (rc = copy_band(c, fb, 0, color_full))) return rc;
-        if (depth_full && (rc = copy_band(c, fb, 1, depth_full))) return rc;
+        if (want_color && (rc = copy_band(c, fb, 0, color_full, frame))) return rc;
+        if (depth_full && (rc = copy_band(c, fb, 1, depth_full, frame))) return rc;
         return SWR_OK;
     };
     if (c->ras_worker) c->ras_worker->post(copies);   // behind the frame's raster share, in order
@@ -1224,7 +1226,7 @@ int single_read(swr_context* c, int img, void* dst) {
     if (tiles_of(c->tg) == 0) return SWR_OK;
     const int fb = c->fb_last;
     HIP_TRY(c, hipEventRecord(c->frame_done[fb], c->stream));
-    if ((rc = copy_band(c, fb, img, dst))) return rc;
+    if ((rc = copy_band(c, fb, img, dst, c->frame_no ? c->frame_no - 1 : 0))) return rc;
     if ((rc = wait_stream(c, c->copy_stream[img], "copy stream"))) return sticky(c) ? sticky(c) : rc;
     return SWR_OK;
 }

@@ -1181,14 +1181,9 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
     __shared__ unsigned long long keys[TILE_W * TILE_H];
     // after the last chunk the per-triangle tables are dead: the resolve keeps the winners' stream slots there
     static_assert(sizeof(float4) * 2 * RASTER_THREADS >= sizeof(uint32_t) * TILE_W * TILE_H, "slots alias tabA + tabB");
-#ifndef SWR_EARLYZ
-#define SWR_EARLYZ 0   // measured (profiles/r02/earlyz_ab.txt): costs 5 % everywhere, gains nothing — see DESIGN.md §6
-#endif
-    // Early-z (hierarchical): per 16x8 sub-tile (4 x-quarters of each wave-high band of rows) the MAXIMUM key high
-    // word = orderable depth of the farthest pixel, 0xFFFFFFFF while any pixel is still uncovered.  Keys only ever
-    // decrease, so a stale word is still an upper bound: no synchronisation between the waves that refresh and read.
-    constexpr bool EARLYZ = SWR_EARLYZ && ZTEST && !METAL;
-    __shared__ uint32_t zmax_tab[RASTER_THREADS / 64][4];
+    // (Early-z — sub-tile maxima of the keys, triangles dropped by a conservative depth bound over their clipped bounding
+    // box — was built twice and measured slower both times: refreshed at every chunk in round 2 (profiles/r02/earlyz_ab.txt),
+    // occluder-first with one barrier per tile in round 3 (profiles/r03/earlyz_occluder_first_ab.txt).  Not in the kernel.)
 
     const int tile = (int)(blockIdx.x >> a.vs_log);
     const int part = (int)(blockIdx.x & ((1u << a.vs_log) - 1u));     // which slice of the tile's rows this workgroup owns
@@ -1260,30 +1255,11 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
 
     // clear fused into the LDS init (Renderer.clear :205-206, :232-236)
     for (int i = tid; i < TILE_W * TILE_H; i += RASTER_THREADS) keys[i] = KEY_EMPTY;
-    if (EARLYZ && tid < 4 * (RASTER_THREADS / 64)) (&zmax_tab[0][0])[tid] = 0xFFFFFFFFu;
     __syncthreads();
 
-    bool first_chunk = true;
     while (VAR != 9 && VAR != 11 && chunk < nchunks) {
         const uint32_t e = chunk * csz + (uint32_t)lane;
         const bool have = (uint32_t)lane < csz && e < m;
-        if (EARLYZ && !first_chunk) {
-            // refresh the four sub-tile words of this wave's band of rows from the keys (16 lanes x 8 pixels each)
-            static_assert(TILE_W == 64 && TILE_H == 8 * (RASTER_THREADS / 64), "sub-tile geometry");
-            const int xq = lane >> 4, ry = (tid >> 6) * 8 + ((lane & 15) >> 1), x0l = xq * 16 + (lane & 1) * 8;
-            const uint4* kp = reinterpret_cast<const uint4*>(&keys[ry * TILE_W + x0l]);
-            const bool rowin = Y0 + ry <= Y1;
-            uint32_t mx = 0u;
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const uint4 k2 = kp[j];                                     // two keys: high words in .y and .w
-                mx = max(mx, (rowin && X0 + x0l + 2 * j <= X1) ? k2.y : 0u);
-                mx = max(mx, (rowin && X0 + x0l + 2 * j + 1 <= X1) ? k2.w : 0u);
-            }
-#pragma unroll
-            for (int off = 1; off < 16; off <<= 1) mx = max(mx, (uint32_t)__shfl_xor((int)mx, off));
-            if ((lane & 15) == 0) __hip_atomic_store(&zmax_tab[tid >> 6][xq], mx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-        }
         TriState t;
         int ya = 1, yb = 0, bxa = 0, bxb = -1;
         bool big = false, large = false;
@@ -1330,35 +1306,6 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             // (huge extents, large clipped area) is walked cooperatively in phase 2
             big = !t.ch.small || maxx - minx >= 16384 || (yb - ya + 1) * (bxb - bxa + 1) > BIG_AREA;
             large = !big && (yb - ya + 1) * (bxb - bxa + 1) >= LARGE_AREA;
-            if (EARLYZ && !first_chunk && !big && ya <= yb && bxa <= bxb) {
-                // Hierarchical z: drop the triangle (for this tile / this wave's rows) when a lower bound of its depth
-                // over every pixel it can cover — its clipped bounding box: spans include pixels OUTSIDE the true
-                // triangle with extrapolated weights (:252-266), so min(za,zb,zc) is NOT a bound — lies strictly above
-                // the farthest depth already stored in the sub-tiles under that box.  Strict '>': at equal depth the
-                // index still decides (:258).
-                const int sq0 = (bxa - X0) >> 4, sq1 = (bxb - X0) >> 4, sb0 = (ya - Y0) >> 3, sb1 = (yb - Y0) >> 3;
-                if (sb1 - sb0 <= 1) {
-                    uint32_t zm = 0u;
-#pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const uint32_t v0 = __hip_atomic_load(&zmax_tab[sb0][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        const uint32_t v1 = __hip_atomic_load(&zmax_tab[sb1][q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                        if (q >= sq0 && q <= sq1) zm = max(zm, max(v0, v1));
-                    }
-                    if (zm < KEY_LIVE_BELOW) {      // every pixel of those sub-tiles already holds a finite depth
-                        // depth = zc + (za - zc) w0 + (zb - zc) w1 with |w0| <= |t00| DX + |t01| DY over the box (affine in
-                        // x, y), likewise w1; plus a generous bound on the rounding of the float evaluation itself
-                        const float DX = (float)max(abs(bxa - t.cx), abs(bxb - t.cx));
-                        const float DY = (float)max(abs(ya - t.cy), abs(yb - t.cy));
-                        const float A0 = fabsf(t.t00) * DX + fabsf(t.t01) * DY;
-                        const float A1 = fabsf(t.t10) * DX + fabsf(t.t11) * DY;
-                        const float dz = (fabsf(t.za - t.zc) * A0 + fabsf(t.zb - t.zc) * A1) * 1.0009765625f;
-                        const float mg = 1.9073486328125e-06f * (fabsf(t.za) * A0 + fabsf(t.zb) * A1 + fabsf(t.zc) * (1.0f + A0 + A1)) + 1e-37f;
-                        const float zlo = (t.zc - dz) - mg;
-                        if (zlo == zlo && orderable_depth(zlo + 0.0f) > zm) yb = ya - 1;   // NaN anywhere: keep the triangle
-                    }
-                }
-            }
         }
 
         // A FEW large triangles among many small ones (a ground plane, a wall, an occluder: at most LARGE_MAX lanes of
@@ -1704,7 +1651,6 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             else dense(std::integral_constant<int, 0>{});
         }
         // the next chunk (wave-uniform, chosen by steal_next): its records, now that the bin entries have arrived
-        first_chunk = false;
         chunk = chunk_next;
         if (have_next) {
             q0_pre = reinterpret_cast<const int4*>(a.geo + prim_pre)[0];

@@ -10,7 +10,8 @@ import numpy as np, swr_amd
 S = swr_amd.scenes
 name = sys.argv[1]
 sc = {"cfg4": lambda: S.cfg4_soup(), "cfg4c": lambda: S.cfg4_soup(depth_only=False), "cfg5": lambda: S.cfg5_sponza_scale(),
-      "cfg3": lambda: S.cfg3_bunny_scale(), "cfg2": lambda: S.cfg2_teapot_scale(), "metal": lambda: S.cfg4_soup()}[name]()
+      "cfg3": lambda: S.cfg3_bunny_scale(), "cfg2": lambda: S.cfg2_teapot_scale(), "metal": lambda: S.cfg4_soup(),
+      "occluded": lambda: S.occluded_soup(z_occluder=0.5), "occluded_near": lambda: S.occluded_soup(z_occluder=0.1)}[name]()
 flags = S.FLAG_METAL_RULES | S.FLAG_NO_COLOR if name == "metal" else sc.flags
 with swr_amd.Context() as ctx:
     ctx.scene_upload(sc.vertices, sc.indices); ctx.target_set(sc.width, sc.height)

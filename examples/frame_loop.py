@@ -102,7 +102,10 @@ def load_ply(path: str):
             raise ValueError("not a PLY file")
         fmt, elements = None, []
         while True:
-            t = f.readline().decode("ascii", "replace").split()
+            line = f.readline()
+            if not line:                          # EOF before end_header (readline returns b"" for ever)
+                raise ValueError("PLY header without end_header")
+            t = line.decode("ascii", "replace").split()
             if not t:
                 continue
             if t[0] == "format":

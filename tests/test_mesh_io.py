@@ -47,6 +47,9 @@ def test_ply_with_normals_uchar_colours_quads_and_extra_elements(fl, tmp_path):
     with pytest.raises(ValueError):
         (tmp_path / "bad.ply").write_text("plx\n")
         fl.load_ply(str(tmp_path / "bad.ply"))
+    with pytest.raises(ValueError):                 # a header that never ends must not loop for ever
+        (tmp_path / "cut.ply").write_text("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\n")
+        fl.load_ply(str(tmp_path / "cut.ply"))
 
 
 def test_obj_and_ply_agree(fl, tmp_path):

@@ -186,3 +186,32 @@ for smax in (1, 2):
     cost_s = 17 + 17 * smax
     print(f"  two rings, short = {smax} px: producer {ps / 1e3:.1f} K, long steps {ls / 1e3:.1f} K, short steps {ss / 1e3:.1f} K  "
           f"-> consumer VALU {(ls * 93 + ss * cost_s) / 1e6:.2f} M  (one ring: {255.8e3 * 93 / 1e6:.2f} M)")
+
+# ---- carry: fewer than CARRY entries left when the rows run out are taken into the next chunk (a small carry table keeps their
+# owners' constants); the wave's last chunk drains.  Chunks are chained four at a time (a wave's share of a tile).
+def sim_carry(chunk_list, UPX=4, CARRY=16, per_wave=2):
+    ps = cs = 0
+    ring = []
+    for ci, lanes in enumerate(chunk_list):
+        nl = len(lanes); ptr = [0] * nl
+        last = (ci % per_wave) == per_wave - 1
+        while True:
+            while len(ring) < 64 and any(ptr[i] < len(lanes[i]) for i in range(nl)):
+                ps += 1
+                for i in range(nl):
+                    if ptr[i] < len(lanes[i]):
+                        if lanes[i][ptr[i]] > 0: ring.append(int(lanes[i][ptr[i]]))
+                        ptr[i] += 1
+            if not ring: break
+            if len(ring) < 64 and not last and len(ring) <= CARRY: break          # carried
+            nq = min(len(ring), 64)
+            J = 64 // pow2ge(nq) if len(ring) < 64 else 1
+            popped, ring = ring[:nq], ring[nq:]
+            ring = ring + [v - UPX * J for v in popped if v > UPX * J]
+            cs += 1
+        if last: ring = []
+    return ps, cs
+for carry, pw in ((0, 2), (16, 2), (32, 2), (63, 2), (16, 1)):
+    ps, cs = sim_carry(chunks, 4, carry, pw)
+    sc_ = total_chunks / len(chunks)
+    print(f"  carry <= {carry:2d} entries, {pw} chunks per wave: producer {ps * sc_ / 1e3:.1f} K, consumer steps {cs * sc_ / 1e3:.1f} K")

@@ -526,6 +526,17 @@ DeviceFrame make_frame(swr_context* c, int si, uint64_t frame, const float m[16]
     f.tile_cursor = tb + CNT_WORDS + 2 * tiles_of(c->tg) + 1;
     f.ranges = (uint2*)sl.ranges.p;
     f.plan = plan_binning(f.ntri, tiles_of(c->tg));
+#ifndef SWR_TUNE_IDLE_BIN_G
+#define SWR_TUNE_IDLE_BIN_G 512
+#endif
+    // An idle context (every earlier frame complete: a single frame, or the first of a burst) bins with twice the
+    // workgroups: with nothing else on the chip k_bin is a chain of round trips at one wave per SIMD, and two waves per
+    // SIMD overlap them; beside a raster the extra waves only take issue slots from it (round 2's sweeps), so frames
+    // posted while others are in flight keep one workgroup per CU.
+    if (c->fixed_mode && f.ntri > 0 && c->synced_upto == c->posted) {
+        const int64_t groups = (f.ntri + 63) / 64;
+        f.plan.G = (int)std::max<int64_t>(1, std::min<int64_t>(SWR_TUNE_IDLE_BIN_G, std::max<int64_t>(f.plan.G, (groups + 7) / 8)));
+    }
     f.bin_matrix = (uint32_t*)sl.bin_matrix.p;
     f.live = (uint32_t*)sl.live.p;
     // Groups of the stream whose projected box misses this context's band (or the framebuffer) are skipped by

@@ -272,13 +272,20 @@ __device__ __forceinline__ void decode_vertices(const GeomFull* __restrict__ ful
 // truncation, y-sort, T(); writes the 32-B GeomRec and returns the triangle's bbox
 // clipped to the band, in pixels: x = x0 | x1 << 16, y = (y0 - row_begin) | (y1 - row_begin) << 16
 // (RANGE_NONE_X when the bbox misses the band).
-__device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p, const float4& xa, const float4& xb, const float4& xc);
+// (MT = the Metal rules, a compile-time flag in k_bin: as a run-time select hipcc evaluates round() for every vertex of
+// every frame, 30 of the 385 vector instructions per triangle)
+template <bool MT>
+__device__ __forceinline__ uint2 setup_triangle_r(const SetupArgs& a, int64_t p, const float4& xa, const float4& xb, const float4& xc);
+__device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p, const float4& xa, const float4& xb, const float4& xc) {
+    return a.metal ? setup_triangle_r<true>(a, p, xa, xb, xc) : setup_triangle_r<false>(a, p, xa, xb, xc);
+}
 __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
     // :223-227 — the three vertex references of the primitive in slot p, in index order (de-indexed at upload)
     return setup_triangle(a, p, a.tri_xyz[3 * p + 0], a.tri_xyz[3 * p + 1], a.tri_xyz[3 * p + 2]);
 }
 // ... with the corners already loaded (k_setup_hist fetches those of its next group while it works on this one)
-__device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p, const float4& xa, const float4& xb, const float4& xc) {
+template <bool MT>
+__device__ __forceinline__ uint2 setup_triangle_r(const SetupArgs& a, int64_t p, const float4& xa, const float4& xb, const float4& xc) {
     uint2 range = make_uint2(RANGE_NONE_X, 0u);
     const uint32_t orig = a.reordered ? __float_as_uint(xa.w) : 0u;
     // vertex colours are passed through by vertex_shader untouched (Shaders.metal:53) and are only
@@ -304,7 +311,7 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p, c
             sx[k] = u * fw;
             sy[k] = v * fh;
             sz[k] = nz;
-            if (a.metal) {                      // vertex_pass: pixels = round(uv * screen) (Shaders.metal:71)
+            if (MT) {                      // vertex_pass: pixels = round(uv * screen) (Shaders.metal:71)
                 sx[k] = roundf(sx[k]);          // half away from zero, like Metal's round()
                 sy[k] = roundf(sy[k]);
             }
@@ -314,7 +321,7 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p, c
 #pragma unroll
     for (int k = 0; k < 3; k++)
         ok = ok && (fabsf(sx[k]) < COORD_LIMIT) && (fabsf(sy[k]) < COORD_LIMIT);
-    if (a.metal) {                              // uint2(pos.xy) (Shaders.metal:102-104): negative is undefined -> skip
+    if (MT) {                              // uint2(pos.xy) (Shaders.metal:102-104): negative is undefined -> skip
 #pragma unroll
         for (int k = 0; k < 3; k++) ok = ok && (sx[k] >= 0.0f) && (sy[k] >= 0.0f);
     }
@@ -327,7 +334,7 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p, c
     // det == 0 (vertices collinear after truncation) is drawn like any other triangle under the CPU rules: T()
     // (:95-100) then holds +-inf / NaN, the clamp of :119-122 maps such colours to 0 / 1 and a NaN depth fails
     // the '<' of :258 — nothing traps in the reference.  (Under the Metal rules det is the shader's `divider`.)
-    if (a.metal) {
+    if (MT) {
         float t00, t01, t10, t11;
         const float det = tinv_of(ix[0], iy[0], ix[1], iy[1], ix[2], iy[2], t00, t01, t10, t11);
         ok = ok && (det != 0.0f) && (fabsf(det) < INFINITY);
@@ -342,7 +349,7 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p, c
     }
     int s0y = iy[o0], s2y = iy[o2];
     const int minx = min(ix[0], min(ix[1], ix[2])), maxx = max(ix[0], max(ix[1], ix[2]));
-    if (a.metal) {
+    if (MT) {
         // roi_pass (Shaders.metal:89-114): the bbox of the snapped vertices; the host skips ROIs whose
         // min-x or min-y is 0 (GpuRenderer.swift:122-124).  det == 0 here is the shader's `divider`
         // (same products): it would make every weight inf/NaN, i.e. no pixel inside -> skip as well.
@@ -733,7 +740,7 @@ struct BinArgs {
 constexpr uint32_t FIXED_CAP_MAX = 61440u;   // cursor halves stay below 2^16: cap + primitives owned by one workgroup < 65536
 enum { CNT_MAXFILL = 3 };
 
-template <int BT>
+template <int BT, bool MT>
 __global__ __launch_bounds__(BT) void k_bin(BinArgs b) {
     extern __shared__ uint32_t hist[];               // [(ntiles + 1) / 2] counters -> cursors, [per] surviving groups, [1] their count, [2 * BT / 64] reduction
     const SetupArgs& a = b.a;
@@ -784,7 +791,7 @@ __global__ __launch_bounds__(BT) void k_bin(BinArgs b) {
             }
             uint2 r = make_uint2(RANGE_NONE_X, 0u);
             if (p < a.ntri) {
-                r = setup_triangle(a, p, xa, xb, xc);
+                r = setup_triangle_r<MT>(a, p, xa, xb, xc);
                 a.ranges[p] = r;
             }
             for_each_tile(unpack_box(r), (uint32_t)p, [&](const PixBox&, uint32_t, int tx, int ty) {
@@ -1945,7 +1952,8 @@ hipError_t prepare_device() {
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_bin<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_bin<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_bin<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)k_fill_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -2004,7 +2012,8 @@ bool launch_bin(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     b.per = live_groups_per_workgroup(f.ntri, f.plan.G);
     b.tag_class = f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0;
     const size_t lds = (size_t)((b.ntiles + 1) / 2) * 4 + (size_t)(b.per + 1) * 4 + 2 * (256 / 64) * 4;
-    SWR_LAUNCH(stop, k_bin<256>, dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b);
+    if (b.a.metal) SWR_LAUNCH(stop, (k_bin<256, true>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b);
+    else SWR_LAUNCH(stop, (k_bin<256, false>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b);
     return stop != nullptr;
 }
 

@@ -473,7 +473,12 @@ int size_bins(swr_context* c) {
     const int tiles = tiles_of(c->tg);
     const int64_t ntri = c->ni / 3;
     const char* bm = getenv("SWR_BIN_MODE");                  // "exact": the four-kernel path with exact-size bins (tests, tools)
-    const bool no_fixed = bm && bm[0] == 'e';
+    // A band of a large scene (what one GPU of N renders, §7) bins faster with round 2's chain of three short kernels than
+    // with the one long k_bin, which shares the chip with the band's raster worse: worst band of N = 2 / 4 / 8 on one GPU
+    // 52.4 / 37.6 / 27.9 us per frame against 59.3 / 38-40 / 30.7 (profiles/r03/b_band_proxy_*); the whole 4K frame is
+    // the other way round (81.9 vs 84.0).  SWR_BIN_MODE=fixed forces k_bin.
+    const bool band_like = tiles < 3000 && ntri >= 200000 && !(bm && bm[0] == 'f');
+    const bool no_fixed = (bm && bm[0] == 'e') || band_like;
     const uint32_t cmax = (c->fixed_allowed && !no_fixed) ? fixed_cap_max(ntri, tiles) : 0u;
     int rc;
     if (cmax) {

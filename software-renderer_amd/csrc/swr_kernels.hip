@@ -1460,7 +1460,7 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
             bool stolen = false;                // the next chunk has been chosen (wave-uniform)
             uint32_t* const q = queue[tid >> 6];
             // ring entry = owner lane | xl << 6 | yl << 12 | (pixels - 1) << 17, xl / yl tile-local
-            static_assert(TILE_W == 64 && TILE_H == 32 && UNIT == 4, "ring entry layout: 6 + 6 + 5 + 6 bits");
+            static_assert(TILE_W == 64 && TILE_H == 32 && UNIT >= 1 && UNIT <= 8, "ring entry layout: 6 + 6 + 5 + 6 bits");
             uint32_t ebase = ((uint32_t)lane | ((uint32_t)((y - Y0) & (TILE_H - 1)) << 12)) - ((uint32_t)X0 << 6);
             // The two chains of draw(triangle:) (:276-277) as row steppers.  Left chain [S0,S1,S2]: the segment the
             // first row of the tile falls into, switched to [S1,S2] at the row y == S1.y (:469-475); right chain [S0,S2].

@@ -1167,8 +1167,15 @@ __device__ __forceinline__ int wave_incl_add(int v) {
 // the "span" of every row of the ROI is the ROI's x-range, the per-pixel maths is the `divider`
 // barycentric with the inside test, the store is bgra8Unorm.
 // EXT = the extended fragment stage (normal / uv varyings, fragment_shader(vin, uniforms)) at the resolve.
-template <bool ZTEST, int VAR = 0, bool METAL = false, bool EXT = false>
-__global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SWR_RASTER_MIN_WAVES) void k_raster(RasterArgs a) {
+// Register budget: 88 VGPRs, not the 96 that five waves per SIMD would allow.  Registers are allocated in blocks of 8, and
+// the binning kernel of the NEXT frame (k_bin: 56) has to fit beside five raster waves on a SIMD (5 x 88 + 56 <= 512):
+// at 91 VGPRs (allocated 96) k_raster alone is as fast, but k_bin finds no room beside it and the pipelined cfg4 frame
+// goes from 0.086 to 0.091 ms (profiles/r03/vgpr_budget_ab.txt).
+#ifndef SWR_RASTER_VGPRS
+#define SWR_RASTER_VGPRS 88
+#endif
+template <bool ZTEST, int VAR, bool METAL, bool EXT>
+__device__ __forceinline__ void raster_tile(const RasterArgs& a) {
     static_assert(!METAL || ZTEST, "the Metal rules always z-test");
 #ifndef SWR_UNIT
 #define SWR_UNIT 4
@@ -1507,11 +1514,12 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
                 if (ZTEST) { ta = tabA[wbase + owner]; tb = tabB[wbase + owner]; }
                 const int cp = __float_as_int(tb.w);
                 const int dyi = yl - (cp >> 16);                                 // y - C.y
-                // Wide visits (screen-filling triangles: the lanes of a step sit in the same row and the same 32 pixels) walk
-                // their groups in a lane-rotated order, so that one ds_min_u64 instruction meets eight addresses eight times
-                // instead of one address 64 times: LDS atomics on one address serialise (profiles/r03/wide_rotation_ab.txt).
+                // (Walking the groups of a wide visit in a lane-rotated order — so that one ds_min_u64 instruction meets eight
+                // addresses instead of one — helps 300 screen-filling triangles (k_raster 281 -> 254 us) and costs THREE VGPRs:
+                // 91 instead of 88, one allocation block too many for k_bin to fit beside five raster waves, 6 % of the
+                // pipelined cfg4 frame (profiles/r03/vgpr_budget_ab.txt).  Off: -DSWR_WIDE_ROT=1 builds it.)
 #ifndef SWR_WIDE_ROT
-#define SWR_WIDE_ROT 1
+#define SWR_WIDE_ROT 0
 #endif
                 const bool rotated = SWR_WIDE_ROT && SL > 0 && __any(nvalid0 > UNIT);           // more than one group somewhere (wave-uniform)
                 const int rot = rotated ? (lane & ((1 << SL) - 1)) : 0;
@@ -1818,6 +1826,14 @@ __global__ __launch_bounds__(RASTER_THREADS, EXT ? SWR_RASTER_MIN_WAVES_EXT : SW
     }
 }
 
+// The kernels proper: the reference's fragment stage (88 VGPRs, see above) and the extended one (its resolve needs more).
+template <bool ZTEST, int VAR = 0, bool METAL = false>
+__global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) __attribute__((amdgpu_num_vgpr(SWR_RASTER_VGPRS)))
+void k_raster(RasterArgs a) { raster_tile<ZTEST, VAR, METAL, false>(a); }
+template <bool ZTEST, bool METAL = false>
+__global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES_EXT)
+void k_raster_ext(RasterArgs a) { raster_tile<ZTEST, 0, METAL, true>(a); }
+
 // ------------------------------------------------------------------------------------------
 // PrimitiveType .vertices (Renderer.swift:295-302) and .line (empty stub, :289-293)
 // ------------------------------------------------------------------------------------------
@@ -2082,15 +2098,15 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     const unsigned tiles = ntiles << a.vs_log;
     const bool ext = f.material.shader != SWR_SHADER_PASSTHROUGH && a.color != nullptr;
     if (f.flags & SWR_FLAG_METAL_RULES) {
-        if (ext) SWR_LAUNCH(stop, (k_raster<true, 0, true, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        if (ext) SWR_LAUNCH(stop, (k_raster_ext<true, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else SWR_LAUNCH(stop, (k_raster<true, 0, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         return stop != nullptr;
     }
     if (ext) {
         if (f.flags & SWR_FLAG_DEPTH_TEST)
-            SWR_LAUNCH(stop, (k_raster<true, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+            SWR_LAUNCH(stop, (k_raster_ext<true, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else
-            SWR_LAUNCH(stop, (k_raster<false, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+            SWR_LAUNCH(stop, (k_raster_ext<false, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         return stop != nullptr;
     }
 #ifdef SWR_ABLATION

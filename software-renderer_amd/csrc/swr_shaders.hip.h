@@ -67,8 +67,9 @@ __device__ __forceinline__ float3 fetch_texel(const FragmentUniforms& u, int x, 
     y = y < 0 ? y + u.tex_h : (y >= u.tex_h ? y - u.tex_h : y);
     x = min(max(x, 0), u.tex_w - 1);
     y = min(max(y, 0), u.tex_h - 1);
-    const float4 t = u.texels[(size_t)y * (size_t)u.tex_w + (size_t)x];
-    return make_float3(t.x, t.y, t.z);
+    // 12 of the texel's 16 bytes (alpha is not used): four texels in flight are 12 registers instead of 16
+    const float* t = reinterpret_cast<const float*>(u.texels + ((size_t)y * (size_t)u.tex_w + (size_t)x));
+    return make_float3(t[0], t[1], t[2]);
 }
 
 // The extended fragment stage (not in the reference; defined in include/swr.h at swr_material and

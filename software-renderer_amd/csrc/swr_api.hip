@@ -483,8 +483,9 @@ int size_bins(swr_context* c) {
     int rc;
     if (cmax) {
         // a primitive enters a tile's region at most once, so a region of `ntri` entries can never overflow: small scenes
-        // get that; large ones six times the mean load of a tile, at least 4096 entries
-        uint64_t want = std::max<uint64_t>(std::max<uint64_t>(64, (uint64_t)(6 * ntri / tiles)), (uint64_t)std::min<int64_t>(ntri, 4096));
+        // get that; large ones six times the mean load of a tile, at least 1024 entries (a fuller tile makes the host grow
+        // the regions and redraw once)
+        uint64_t want = std::max<uint64_t>(std::max<uint64_t>(64, (uint64_t)(6 * ntri / tiles)), (uint64_t)std::min<int64_t>(ntri, 1024));
         want = std::min<uint64_t>((want + 63) & ~63ull, cmax);
         if (!c->fixed_mode || c->cap_tile < want || c->cap_tile > cmax) c->cap_tile = (uint32_t)want;   // a grown region survives a new transform
         if ((rc = ensure_bins(c, (size_t)tiles * c->cap_tile))) return rc;

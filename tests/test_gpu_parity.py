@@ -365,7 +365,7 @@ def crowded_tile_scene(swr, ntri, flags=DT):
 
 def test_fixed_stride_bins_regrow_and_fall_back(swr, oracle):
     """k_bin's tile regions: a tile that receives more entries than its region holds makes the host grow the regions
-    and redraw (20 000 triangles in one tile against the initial 4 096); a tile that needs more than a region can ever
+    and redraw (20 000 triangles in two tiles against the initial 1 024); a tile that needs more than a region can ever
     hold (cursor halves are 16 bits) switches the context to exact-size bins."""
     for ntri in (20000, 140000):
         s = crowded_tile_scene(swr, ntri)

@@ -1079,9 +1079,7 @@ __device__ __forceinline__ void load_tri(const GeomFull* __restrict__ full, uint
     t.ch.s1x = pick(o1, vx[0], vx[1], vx[2]); t.ch.s1y = pick(o1, vy[0], vy[1], vy[2]);
     t.ch.s2x = pick(o2, vx[0], vx[1], vx[2]); t.ch.s2y = pick(o2, vy[0], vy[1], vy[2]);
     t.ch.small = (fl & GEOM_SMALL) != 0;
-    t.ch.r01 = __builtin_amdgcn_rcpf((float)(t.ch.s1y - t.ch.s0y));
-    t.ch.r12 = __builtin_amdgcn_rcpf((float)(t.ch.s2y - t.ch.s1y));
-    t.ch.r02 = __builtin_amdgcn_rcpf((float)(t.ch.s2y - t.ch.s0y));
+    t.ch.r01 = t.ch.r12 = t.ch.r02 = 0.0f;     // only the cooperative walk uses them: computed there, once per large triangle
     t.cfx = (float)vx[2] + 0.5f;
     t.cfy = (float)vy[2] + 0.5f;
     t.cx = vx[2];
@@ -1170,7 +1168,8 @@ __device__ __forceinline__ int wave_incl_add(int v) {
 // Register budget: 88 VGPRs, not the 96 that five waves per SIMD would allow.  Registers are allocated in blocks of 8, and
 // the binning kernel of the NEXT frame (k_bin: 56) has to fit beside five raster waves on a SIMD (5 x 88 + 56 <= 512):
 // at 91 VGPRs (allocated 96) k_raster alone is as fast, but k_bin finds no room beside it and the pipelined cfg4 frame
-// goes from 0.086 to 0.091 ms (profiles/r03/vgpr_budget_ab.txt).
+// goes from 0.086 to 0.091 ms (profiles/r03/vgpr_budget_ab.txt).  Check with `make asm` after every change: 86 now
+// (Metal rules 88).
 #ifndef SWR_RASTER_VGPRS
 #define SWR_RASTER_VGPRS 88
 #endif
@@ -1372,8 +1371,9 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
             u.ch.s0x = bcast_i(t.ch.s0x, src); u.ch.s0y = bcast_i(t.ch.s0y, src);
             u.ch.s1x = bcast_i(t.ch.s1x, src); u.ch.s1y = bcast_i(t.ch.s1y, src);
             u.ch.s2x = bcast_i(t.ch.s2x, src); u.ch.s2y = bcast_i(t.ch.s2y, src);
-            u.ch.r01 = bcast_f(t.ch.r01, src); u.ch.r12 = bcast_f(t.ch.r12, src);
-            u.ch.r02 = bcast_f(t.ch.r02, src);
+            u.ch.r01 = __builtin_amdgcn_rcpf((float)(u.ch.s1y - u.ch.s0y));     // (wave-uniform; same values the per-lane setup used to compute)
+            u.ch.r12 = __builtin_amdgcn_rcpf((float)(u.ch.s2y - u.ch.s1y));
+            u.ch.r02 = __builtin_amdgcn_rcpf((float)(u.ch.s2y - u.ch.s0y));
             u.ch.small = bcast_i(t.ch.small ? 1 : 0, src) != 0;
             u.cfx = bcast_f(t.cfx, src); u.cfy = bcast_f(t.cfy, src);
             u.t00 = bcast_f(t.t00, src); u.t01 = bcast_f(t.t01, src);
@@ -1514,12 +1514,13 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
                 if (ZTEST) { ta = tabA[wbase + owner]; tb = tabB[wbase + owner]; }
                 const int cp = __float_as_int(tb.w);
                 const int dyi = yl - (cp >> 16);                                 // y - C.y
-                // (Walking the groups of a wide visit in a lane-rotated order — so that one ds_min_u64 instruction meets eight
-                // addresses instead of one — helps 300 screen-filling triangles (k_raster 281 -> 254 us) and costs THREE VGPRs:
-                // 91 instead of 88, one allocation block too many for k_bin to fit beside five raster waves, 6 % of the
-                // pipelined cfg4 frame (profiles/r03/vgpr_budget_ab.txt).  Off: -DSWR_WIDE_ROT=1 builds it.)
+                // Wide visits (screen-filling triangles: the lanes of a step sit in the same row and the same 32 pixels) walk
+                // their groups in a lane-rotated order, so that one ds_min_u64 instruction meets eight addresses instead of
+                // one: 300 screen-filling triangles 281 -> 252 us.  It costs three VGPRs: affordable only inside the 88-register
+                // budget above (it once pushed the kernel to 91 and the pipelined cfg4 frame up by 6 %,
+                // profiles/r03/vgpr_budget_ab.txt; moving the chains' reciprocals out of the per-lane setup made the room).
 #ifndef SWR_WIDE_ROT
-#define SWR_WIDE_ROT 0
+#define SWR_WIDE_ROT 1
 #endif
                 const bool rotated = SWR_WIDE_ROT && SL > 0 && __any(nvalid0 > UNIT);           // more than one group somewhere (wave-uniform)
                 const int rot = rotated ? (lane & ((1 << SL) - 1)) : 0;

@@ -65,7 +65,10 @@ struct Worker {
                 if (q.empty()) {
                     // spin briefly before sleeping: frames arrive every few tens of microseconds
                     lk.unlock();
-                    for (int spin = 0; spin < 4000; spin++) {
+#ifndef SWR_TUNE_HELPER_SPIN
+#define SWR_TUNE_HELPER_SPIN 4000
+#endif
+                    for (int spin = 0; spin < SWR_TUNE_HELPER_SPIN; spin++) {
                         __builtin_ia32_pause();
                         if (pending.load(std::memory_order_acquire)) break;
                     }

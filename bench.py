@@ -18,7 +18,9 @@ renders its band; no collective on the data path (bands are disjoint).  Two ways
 The total work is fixed as N grows => "scaling": "strong".
 
 Prints ONE JSON line on rank 0.
-  value / ms_per_step   untimed region (no HIP event on any stream), frames pipelined
+  value / ms_per_step   W untimed + K timed frames, no HIP event on any stream, frames pipelined, GPU clocks up (the
+                        pass runs after the latency and sampled-roofline passes)
+  ms_per_step_first_pass  the same W + K frames as the process's first GPU work (clock ramp after idle included)
   latency_ms            one frame alone, swr_draw -> swr_sync
   roofline              dominant kernel k_raster from a SEPARATE sampled pass (two HIP events around every n-th
                         launch, on the raster stream): algorithmic framebuffer bytes of the band / mean duration
@@ -201,10 +203,13 @@ def main():
     flags = scene.flags
     bytes_per_px = 4 if (flags & S.FLAG_NO_COLOR) else 8
 
-    # ---- pass 1: the headline, measured before anything is instrumented -------------------------------------------
-    dt, _, _ = run(flags, args.steps, args.warmup, level=0)
-    ms_per_step = dt / args.steps * 1e3
-    mpix = W * H * args.steps / dt / 1e6
+    # ---- pass 0: the driver's shape straight out of idle ------------------------------------------------------------
+    # An MI355X that has been idle for ~50 ms runs its first ~150 frames 10-15 % slower (clock / power-state ramp:
+    # profiles/r03/gpu_warmup_after_idle.txt — a hot context that sleeps 50 ms shows the same ramp as a fresh one), and
+    # the process has just spent seconds on the host building the scene.  This pass is the W + K frames measured in that
+    # state; it is reported (ms_per_step_first_pass) and never hidden, but `value` is the steady state below.
+    dt_first, _, _ = run(flags, args.steps, args.warmup, level=0)
+    frames_before_headline = args.steps + args.warmup
 
     # one frame alone: enqueue -> host sees it finished (no other frame in flight)
     lat = []
@@ -215,13 +220,21 @@ def main():
         ctx.sync()
         lat.append(time.perf_counter() - t0)
     latency_ms = max_over_ranks(float(np.median(lat[2:]))) * 1e3
+    frames_before_headline += 12
 
-    # ---- pass 2: k_raster's launch duration, sampled (an event pair on the raster stream costs a pipelined frame
+    # ---- pass 1: k_raster's launch duration, sampled (an event pair on the raster stream costs a pipelined frame
     # ~15 us, so only every n-th launch is bracketed and this pass never feeds `value`) ---------------------------------
     SAMPLE = max(1, int(os.environ.get("SWR_BENCH_TIMING_SAMPLE", "8")))
-    roof_steps = max(args.steps, 64)
+    roof_steps = max(args.steps, 128)
     SAMPLE = max(1, min(SAMPLE, roof_steps // 8))
     dt_s, sums, frames = run(flags, roof_steps, 4, level=1, sample=SAMPLE)
+    frames_before_headline += roof_steps + 4
+
+    # ---- pass 2: the headline — W untimed + exactly K timed frames, no HIP event on any stream, GPU clocks up ---------
+    dt, _, _ = run(flags, args.steps, args.warmup, level=0)
+    ms_per_step = dt / args.steps * 1e3
+    mpix = W * H * args.steps / dt / 1e6
+
     raster_ms = sums["raster_ms"] / max(frames, 1)
     achieved = largest_band_px * bytes_per_px / (raster_ms * 1e-3) / 1e9 if raster_ms > 0 else 0.0
     traffic = load_profile_json("traffic.json") or {}
@@ -352,6 +365,10 @@ def main():
         "metric": "Mpixels/s at 4K on the 1M-triangle synthetic scene (frames/s in extra)",
         "value": round(mpix, 2), "unit": "Mpixels/s", "n_gpus": n_gpus, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "ms_per_step_first_pass": round(dt_first / args.steps * 1e3, 4), "frames_before_timed_pass": frames_before_headline,
+        "pass_order_note": "the same W + K frames are timed twice: first straight out of idle (ms_per_step_first_pass: the GPU's "
+                           "clock ramp after idle costs the first ~150 frames 10-15 %, profiles/r03/gpu_warmup_after_idle.txt), then again "
+                           "after the latency and sampled-roofline passes (value / ms_per_step: steady state, what a frame loop sees)",
         "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "value_host_visible": (extra.get("host_visible") or {}).get("Mpixels_per_s"),
         "value_note": "value = device-resident frames (inputs and framebuffer in HBM, as the bench contract asks); value_host_visible = "

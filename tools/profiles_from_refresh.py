@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Copy one tools/round_refresh.sh result set into profiles/ and rewrite profiles/traffic.json / profiles/valu.json from it.
+    python tools/profiles_from_refresh.py <refresh prefix> <profiles prefix> [round dir]      e.g.  g e r03"""
+import ast, glob, json, os, shutil, subprocess, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, dst = sys.argv[1], sys.argv[2]
+rnd = sys.argv[3] if len(sys.argv) > 3 else "r03"
+out = os.path.join(ROOT, "profiles", rnd)
+for f in glob.glob(os.path.join(ROOT, "gpurun_out", "refresh", src + "_*")):
+    shutil.copy(f, os.path.join(out, dst + os.path.basename(f)[len(src):]))
+commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+raw = json.load(open(os.path.join(out, f"{dst}_traffic_raw_KB.json")))
+kr = next(k for k in raw if "k_raster<true, 0, false>" in k)
+t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
+t.update({"commit": commit, "all_kernels_raw_KB": raw,
+          "k_raster_fetch_bytes_raw": raw[kr]["FETCH_SIZE"] * 1024, "k_raster_write_bytes": raw[kr]["WRITE_SIZE"] * 1024,
+          "k_raster_bytes_per_launch": (raw[kr]["FETCH_SIZE"] + raw[kr]["WRITE_SIZE"]) * 1024})
+json.dump(t, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
+v = json.load(open(os.path.join(ROOT, "profiles", "valu.json")))
+for line in open(os.path.join(out, f"{dst}_sq_counters.txt")):
+    if "k_raster<true, 0, false>" in line and "SQ_INSTS_VALU" in line:
+        d = ast.literal_eval(line[line.index("{"):])
+        v.update({"commit": commit, "k_raster_valu_wave_insts_per_launch": d["SQ_INSTS_VALU"],
+                  "k_raster_salu_insts_per_launch": d["SQ_INSTS_SALU"], "k_raster_lds_insts_per_launch": d["SQ_INSTS_LDS"]})
+json.dump(v, open(os.path.join(ROOT, "profiles", "valu.json"), "w"), indent=1)
+print("profiles/%s/%s_* <- refresh %s_*, commit %s: k_raster %.2f M VALU, %.1f MB HBM" % (
+    rnd, dst, src, commit, v["k_raster_valu_wave_insts_per_launch"] / 1e6, t["k_raster_bytes_per_launch"] / 1e6))

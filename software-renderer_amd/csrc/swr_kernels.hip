@@ -1173,9 +1173,10 @@ __device__ __forceinline__ int wave_incl_add(int v) {
 #ifndef SWR_RASTER_VGPRS
 #define SWR_RASTER_VGPRS 88
 #endif
-template <bool ZTEST, int VAR, bool METAL, bool EXT>
+template <bool ZTEST, int VAR, bool METAL, bool EXT, bool COLOR>
 __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
     static_assert(!METAL || ZTEST, "the Metal rules always z-test");
+    static_assert(!EXT || COLOR, "the extended fragment stage only exists for colour frames");
 #ifndef SWR_UNIT
 #define SWR_UNIT 4
 #endif
@@ -1676,7 +1677,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
     __syncthreads();
 
     // ---- resolve: key -> pixel, one coalesced write per pixel --------------------------------
-    const bool want_color = a.color != nullptr;
+    constexpr bool want_color = COLOR;          // a.color != nullptr; depth-only frames (SWR_FLAG_NO_COLOR) have their own kernels
     const int W = a.tg.width;
     const bool vec_ok = (W & 3) == 0;
     // Colour frames: the stream slots of ALL this thread's winners first (original index -> slot is a gather from a
@@ -1695,92 +1696,128 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
 #pragma unroll
         for (int g = 0; g < 8; g++) slots[(tid + (g >> 2) * RASTER_THREADS) * 4 + (g & 3)] = sl[g];
     }
-    for (int i = tid; VAR != 8 && VAR != 10 && VAR != 11 && i < TILE_W * TILE_H / 4; i += RASTER_THREADS) {
-        const int ly = (i * 4) / TILE_W, lx = (i * 4) % TILE_W;
-        const int y = Y0 + ly, x = X0 + lx;
-        if (y < Yp0 || y > Yp1 || x > X1) continue;
-        uint32_t cpix[4];
-        float dpix[4];
+    // A thread's two 4-pixel groups are resolved TOGETHER, pixel by pixel: the record / colour gathers of a new winner
+    // in group 0 and in group 1 are issued back to back and waited for once, so the chain a thread walks is four
+    // gather latencies instead of eight (colour frames: the wait for those gathers, not the arithmetic, is what the
+    // colour store costs over a depth-only frame — SQ_WAIT_ANY 73 M -> 146 M wave-cycles for +32 % VALU).
+    // Which kernels walk their two groups together is a measurement (profiles/r03/resolve_joint_ab.txt): it changes the
+    // register allocation of the whole kernel, and with it how many binning waves fit beside the raster's.
+#ifndef SWR_NG_DEPTH
+#define SWR_NG_DEPTH 2
+#define SWR_NG_COLOR 1
+#define SWR_NG_METAL_COLOR 2
+#define SWR_NG_EXT 1
+#endif
+    constexpr int NG = EXT ? SWR_NG_EXT : (!COLOR ? SWR_NG_DEPTH : (METAL ? SWR_NG_METAL_COLOR : SWR_NG_COLOR));
+    static_assert(NG == 1 || NG == 2, "a thread owns two groups");
+    for (int i0 = tid; VAR != 8 && VAR != 10 && VAR != 11 && i0 < TILE_W * TILE_H / 4; i0 += NG * RASTER_THREADS) {
+        int ly[NG], lx[NG], y[NG], x[NG];
+        bool on[NG];
+        uint32_t cpix[NG][4];
+        float dpix[NG][4];
         // neighbouring pixels usually share the winning primitive: its record, T() and vertex
         // colours are fetched / computed once per run of equal primitives
-        uint32_t cached_prim = 0xFFFFFFFFu, slot = 0u;
-        float4 q2 = make_float4(0, 0, 0, 0), q3 = q2, ca = q2, cb = q2, cc = q2, na = q2, nb = q2, nc = q2;
-        float cfx = 0.0f, cfy = 0.0f;
-        MetalTri mt = {};
-        // the four winners' stream slots first, as four independent loads: the per-run chain below is then
-        // record / colours (two parallel gathers) instead of inv -> record -> colours
-        unsigned long long key4[4];
-        uint32_t slot4[4];
+        uint32_t cached_prim[NG], slot[NG];
+        float4 q2[NG], q3[NG], ca[NG], cb[NG], cc[NG], na[NG], nb[NG], nc[NG];
+        int4 g0[NG];
+        float cfx[NG], cfy[NG];
+        MetalTri mt[NG];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            key4[k] = keys[ly * TILE_W + lx + k];
-            const uint32_t prim = ZTEST ? (uint32_t)key4[k] : 0xFFFFFFFFu - (uint32_t)key4[k];
-            slot4[k] = (want_color && a.reordered) ? slots[ly * TILE_W + lx + k] : prim;
+        for (int g = 0; g < NG; g++) {
+            const int i = i0 + g * RASTER_THREADS;
+            ly[g] = (i * 4) / TILE_W; lx[g] = (i * 4) % TILE_W;
+            y[g] = Y0 + ly[g]; x[g] = X0 + lx[g];
+            on[g] = !(y[g] < Yp0 || y[g] > Yp1 || x[g] > X1);
+            cached_prim[g] = 0xFFFFFFFFu; slot[g] = 0u;
+            q2[g] = q3[g] = ca[g] = cb[g] = cc[g] = na[g] = nb[g] = nc[g] = make_float4(0, 0, 0, 0);
+            g0[g] = make_int4(0, 0, 0, 0);
+            cfx[g] = cfy[g] = 0.0f;
+            mt[g] = MetalTri{};
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const unsigned long long key = key4[k];
-            uint32_t c = 0u;               // Pixel(0,0,0,0) (:205)
-            float d = INFINITY;            // (:206)
-            if ((uint32_t)(key >> 32) < KEY_LIVE_BELOW && x + k <= X1) {
-                const uint32_t prim = ZTEST ? (uint32_t)key : 0xFFFFFFFFu - (uint32_t)key;
+            uint32_t prim[NG];
+            float d[NG];
+            bool need_rec[NG], miss[NG];
+            // which groups meet a new winner at this pixel; their gathers go out together
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                const unsigned long long key = keys[ly[g] * TILE_W + lx[g] + k];
                 const uint32_t hi = (uint32_t)(key >> 32);
-                bool need_rec = want_color;
-                if (ZTEST) {
-                    d = depth_from_orderable(hi);
-                    need_rec = need_rec || (d == 0.0f);   // sign of zero comes from the winner
+                const bool live = on[g] && hi < KEY_LIVE_BELOW && x[g] + k <= X1;
+                prim[g] = ZTEST ? (uint32_t)key : 0xFFFFFFFFu - (uint32_t)key;
+                d[g] = INFINITY;           // (:206)
+                need_rec[g] = live && want_color;
+                if (ZTEST && live) {
+                    d[g] = depth_from_orderable(hi);
+                    need_rec[g] = need_rec[g] || (d[g] == 0.0f);   // sign of zero comes from the winner
                 }
-                if (need_rec) {
-                    if (prim != cached_prim) {
-                        cached_prim = prim;
-                        int4 g0;
-                        int vx[3], vy[3];
-                        slot = (want_color || !a.reordered) ? slot4[k] : a.inv[prim];   // depth-only: only the rare d == 0 winner
-                        load_vertices(a.geo, a.geo_full, slot, g0, q3, vx, vy);
-                        if (METAL) {
-                            metal_consts(vx, vy, q3.x, q3.y, q3.z, mt);
-                        } else {
-                            // T() of the winning primitive, recomputed (same expressions, same bits)
-                            tinv_of(vx[0], vy[0], vx[1], vy[1], vx[2], vy[2], q2.x, q2.y, q2.z, q2.w);
-                            cfx = (float)vx[2] + 0.5f;
-                            cfy = (float)vy[2] + 0.5f;
-                        }
-                        if (want_color) {
-                            // vertex colours of a,b,c (RenderPass.vertices[RenderPass.indices[3p+k]].color), one 48-B record
-                            ca = a.tri_rgb[3 * (size_t)slot + 0];
-                            cb = a.tri_rgb[3 * (size_t)slot + 1];
-                            cc = a.tri_rgb[3 * (size_t)slot + 2];
-                            if (EXT) {
-                                na = a.tri_nrm[3 * (size_t)slot + 0];
-                                nb = a.tri_nrm[3 * (size_t)slot + 1];
-                                nc = a.tri_nrm[3 * (size_t)slot + 2];
-                            }
+                miss[g] = need_rec[g] && prim[g] != cached_prim[g];
+            }
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                if (miss[g]) {
+                    cached_prim[g] = prim[g];
+                    // colour frames hold the winners' stream slots in LDS (above); depth-only: only the rare d == 0 winner
+                    slot[g] = !a.reordered ? prim[g] : (want_color ? slots[ly[g] * TILE_W + lx[g] + k] : a.inv[prim[g]]);
+                    g0[g] = reinterpret_cast<const int4*>(a.geo + slot[g])[0];
+                    q3[g] = reinterpret_cast<const float4*>(a.geo + slot[g])[1];
+                    if (want_color) {
+                        // vertex colours of a,b,c (RenderPass.vertices[RenderPass.indices[3p+k]].color), one 48-B record
+                        ca[g] = a.tri_rgb[3 * (size_t)slot[g] + 0];
+                        cb[g] = a.tri_rgb[3 * (size_t)slot[g] + 1];
+                        cc[g] = a.tri_rgb[3 * (size_t)slot[g] + 2];
+                        if (EXT) {
+                            na[g] = a.tri_nrm[3 * (size_t)slot[g] + 0];
+                            nb[g] = a.tri_nrm[3 * (size_t)slot[g] + 1];
+                            nc[g] = a.tri_nrm[3 * (size_t)slot[g] + 2];
                         }
                     }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                if (miss[g]) {
+                    int vx[3], vy[3];
+                    decode_vertices(a.geo_full, slot[g], g0[g], q3[g], vx, vy);
+                    if (METAL) {
+                        metal_consts(vx, vy, q3[g].x, q3[g].y, q3[g].z, mt[g]);
+                    } else {
+                        // T() of the winning primitive, recomputed (same expressions, same bits)
+                        tinv_of(vx[0], vy[0], vx[1], vy[1], vx[2], vy[2], q2[g].x, q2[g].y, q2[g].z, q2[g].w);
+                        cfx[g] = (float)vx[2] + 0.5f;
+                        cfy[g] = (float)vy[2] + 0.5f;
+                    }
+                }
+            }
+#pragma unroll
+            for (int g = 0; g < NG; g++) {
+                uint32_t c = 0u;               // Pixel(0,0,0,0) (:205)
+                if (need_rec[g]) {
                     float w0, w1, w2;
                     if (METAL) {
-                        metal_weights(mt, x + k, y, w0, w1, w2);          // Shaders.metal:133-149
+                        metal_weights(mt[g], x[g] + k, y[g], w0, w1, w2);          // Shaders.metal:133-149
                     } else {
-                        const float dx = ((float)(x + k) + 0.5f) - cfx;
-                        const float dy = ((float)y + 0.5f) - cfy;
-                        w0 = q2.x * dx + q2.y * dy;
-                        w1 = q2.z * dx + q2.w * dy;
+                        const float dx = ((float)(x[g] + k) + 0.5f) - cfx[g];
+                        const float dy = ((float)y[g] + 0.5f) - cfy[g];
+                        w0 = q2[g].x * dx + q2[g].y * dy;
+                        w1 = q2[g].z * dx + q2[g].w * dy;
                         w2 = 1.0f - w0 - w1;
                     }
-                    if (ZTEST) d = q3.x * w0 + q3.y * w1 + q3.z * w2;
+                    if (ZTEST) d[g] = q3[g].x * w0 + q3[g].y * w1 + q3[g].z * w2;
                     if (want_color) {
                         VertexOut vin;
-                        vin.pos = make_float4((float)(x + k) + 0.5f, (float)y + 0.5f, d, 1.0f);
-                        vin.color = make_float3(ca.x * w0 + cb.x * w1 + cc.x * w2,     // :266
-                                                ca.y * w0 + cb.y * w1 + cc.y * w2,
-                                                ca.z * w0 + cb.z * w1 + cc.z * w2);
+                        vin.pos = make_float4((float)(x[g] + k) + 0.5f, (float)y[g] + 0.5f, d[g], 1.0f);
+                        vin.color = make_float3(ca[g].x * w0 + cb[g].x * w1 + cc[g].x * w2,     // :266
+                                                ca[g].y * w0 + cb[g].y * w1 + cc[g].y * w2,
+                                                ca[g].z * w0 + cb[g].z * w1 + cc[g].z * w2);
                         float4 f;
                         if (EXT) {   // varyings interpolated like colour; u = tri_nrm.w, v = tri_rgb.w
-                            vin.normal = make_float3(na.x * w0 + nb.x * w1 + nc.x * w2,
-                                                     na.y * w0 + nb.y * w1 + nc.y * w2,
-                                                     na.z * w0 + nb.z * w1 + nc.z * w2);
-                            vin.uv = make_float2(na.w * w0 + nb.w * w1 + nc.w * w2,
-                                                 ca.w * w0 + cb.w * w1 + cc.w * w2);
+                            vin.normal = make_float3(na[g].x * w0 + nb[g].x * w1 + nc[g].x * w2,
+                                                     na[g].y * w0 + nb[g].y * w1 + nc[g].y * w2,
+                                                     na[g].z * w0 + nb[g].z * w1 + nc[g].z * w2);
+                            vin.uv = make_float2(na[g].w * w0 + nb[g].w * w1 + nc[g].w * w2,
+                                                 ca[g].w * w0 + cb[g].w * w1 + cc[g].w * w2);
                             f = fragment_shader(vin, a.fs);
                         } else {
                             f = fragment_shader(vin);
@@ -1793,47 +1830,44 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
                         c = (uint32_t)ub | ((uint32_t)ug << 8) | ((uint32_t)ur << 16) | ((uint32_t)ua << 24);
                     }
                 }
+                cpix[g][k] = c;
+                dpix[g][k] = d[g];
             }
-            cpix[k] = c;
-            dpix[k] = d;
         }
-        const size_t at = (size_t)(y - a.tg.row_begin) * (size_t)W + (size_t)x;   // App.swift:351-360
-        if (vec_ok && x + 3 <= X1) {
-            // streaming stores: nothing on the GPU reads the framebuffer again, and 33 MB of dirty lines left in the
-            // L2s would be written back at the end of the kernel, in front of the next one
-            typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-            typedef float f32x4 __attribute__((ext_vector_type(4)));
-#ifndef SWR_NT_STORES
-#define SWR_NT_STORES 1
-#endif
-            if (SWR_NT_STORES) {
+#pragma unroll
+        for (int g = 0; g < NG; g++) {
+            if (!on[g]) continue;
+            const size_t at = (size_t)(y[g] - a.tg.row_begin) * (size_t)W + (size_t)x[g];   // App.swift:351-360
+            if (vec_ok && x[g] + 3 <= X1) {
+                // streaming stores: nothing on the GPU reads the framebuffer again, and 33 MB of dirty lines left in the
+                // L2s would be written back at the end of the kernel, in front of the next one
+                typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
                 if (want_color) {
-                    u32x4 cv = {cpix[0], cpix[1], cpix[2], cpix[3]};
+                    u32x4 cv = {cpix[g][0], cpix[g][1], cpix[g][2], cpix[g][3]};
                     __builtin_nontemporal_store(cv, reinterpret_cast<u32x4*>(a.color + at * 4));
                 }
-                f32x4 dv = {dpix[0], dpix[1], dpix[2], dpix[3]};
+                f32x4 dv = {dpix[g][0], dpix[g][1], dpix[g][2], dpix[g][3]};
                 __builtin_nontemporal_store(dv, reinterpret_cast<f32x4*>(a.depth + at));
             } else {
-                if (want_color)
-                    *reinterpret_cast<uint4*>(a.color + at * 4) = make_uint4(cpix[0], cpix[1], cpix[2], cpix[3]);
-                *reinterpret_cast<float4*>(a.depth + at) = make_float4(dpix[0], dpix[1], dpix[2], dpix[3]);
-            }
-        } else {
-            for (int k = 0; k < 4 && x + k <= X1; k++) {
-                if (want_color) reinterpret_cast<uint32_t*>(a.color)[at + k] = cpix[k];
-                a.depth[at + k] = dpix[k];
+                for (int k = 0; k < 4 && x[g] + k <= X1; k++) {
+                    if (want_color) reinterpret_cast<uint32_t*>(a.color)[at + k] = cpix[g][k];
+                    a.depth[at + k] = dpix[g][k];
+                }
             }
         }
     }
 }
 
-// The kernels proper: the reference's fragment stage (88 VGPRs, see above) and the extended one (its resolve needs more).
-template <bool ZTEST, int VAR = 0, bool METAL = false>
+// The kernels proper: the reference's fragment stage — colour and depth-only frames (SWR_FLAG_NO_COLOR) as separate kernels, so
+// that each has its own register allocation (tools/vgprs.sh: 86 depth-only, 91 colour, 88 Metal rules; the budget of 88 above is
+// the depth-only kernel's) — and the extended one (its resolve needs more).
+template <bool ZTEST, int VAR = 0, bool METAL = false, bool COLOR = false>
 __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) __attribute__((amdgpu_num_vgpr(SWR_RASTER_VGPRS)))
-void k_raster(RasterArgs a) { raster_tile<ZTEST, VAR, METAL, false>(a); }
+void k_raster(RasterArgs a) { raster_tile<ZTEST, VAR, METAL, false, COLOR>(a); }
 template <bool ZTEST, bool METAL = false>
 __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES_EXT)
-void k_raster_ext(RasterArgs a) { raster_tile<ZTEST, 0, METAL, true>(a); }
+void k_raster_ext(RasterArgs a) { raster_tile<ZTEST, 0, METAL, true, true>(a); }
 
 // ------------------------------------------------------------------------------------------
 // PrimitiveType .vertices (Renderer.swift:295-302) and .line (empty stub, :289-293)
@@ -2100,7 +2134,8 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     const bool ext = f.material.shader != SWR_SHADER_PASSTHROUGH && a.color != nullptr;
     if (f.flags & SWR_FLAG_METAL_RULES) {
         if (ext) SWR_LAUNCH(stop, (k_raster_ext<true, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-        else SWR_LAUNCH(stop, (k_raster<true, 0, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        else if (a.color) SWR_LAUNCH(stop, (k_raster<true, 0, true, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        else SWR_LAUNCH(stop, (k_raster<true, 0, true, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         return stop != nullptr;
     }
     if (ext) {
@@ -2114,7 +2149,7 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     // timing-only ablations of k_raster<ztest> (results invalid): compiled only into lib/libswr_hip_ablation.so
     // (`make ablation`, used by tools/variants.sh); the product library has neither the kernels nor the switch
     static const int variant = getenv("SWR_DEBUG_VARIANT") ? atoi(getenv("SWR_DEBUG_VARIANT")) : 0;
-    if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant > 0) {
+    if ((f.flags & SWR_FLAG_DEPTH_TEST) && variant > 0 && !a.color) {
         switch (variant) {
 #define SWR_V(N) case N: hipLaunchKernelGGL((k_raster<true, N>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a); return false;
             SWR_V(1) SWR_V(2) SWR_V(3) SWR_V(4) SWR_V(5) SWR_V(8) SWR_V(9) SWR_V(10) SWR_V(11)
@@ -2123,10 +2158,13 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
         }
     }
 #endif
-    if (f.flags & SWR_FLAG_DEPTH_TEST)
-        SWR_LAUNCH(stop, k_raster<true>, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-    else
-        SWR_LAUNCH(stop, k_raster<false>, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+    if (f.flags & SWR_FLAG_DEPTH_TEST) {
+        if (a.color) SWR_LAUNCH(stop, (k_raster<true, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        else SWR_LAUNCH(stop, (k_raster<true, 0, false, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+    } else {
+        if (a.color) SWR_LAUNCH(stop, (k_raster<false, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        else SWR_LAUNCH(stop, (k_raster<false, 0, false, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+    }
     return stop != nullptr;
 }
 

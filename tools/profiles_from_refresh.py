@@ -10,7 +10,7 @@ for f in glob.glob(os.path.join(ROOT, "gpurun_out", "refresh", src + "_*")):
     shutil.copy(f, os.path.join(out, dst + os.path.basename(f)[len(src):]))
 commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
 raw = json.load(open(os.path.join(out, f"{dst}_traffic_raw_KB.json")))
-kr = next(k for k in raw if "k_raster<true, 0, false>" in k)
+kr = next(k for k in raw if "k_raster<true, 0, false" in k)
 t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
 t.update({"commit": commit, "all_kernels_raw_KB": raw,
           "k_raster_fetch_bytes_raw": raw[kr]["FETCH_SIZE"] * 1024, "k_raster_write_bytes": raw[kr]["WRITE_SIZE"] * 1024,
@@ -18,7 +18,7 @@ t.update({"commit": commit, "all_kernels_raw_KB": raw,
 json.dump(t, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 v = json.load(open(os.path.join(ROOT, "profiles", "valu.json")))
 for line in open(os.path.join(out, f"{dst}_sq_counters.txt")):
-    if "k_raster<true, 0, false>" in line and "SQ_INSTS_VALU" in line:
+    if "k_raster<true, 0, false" in line and "SQ_INSTS_VALU" in line:
         d = ast.literal_eval(line[line.index("{"):])
         v.update({"commit": commit, "k_raster_valu_wave_insts_per_launch": d["SQ_INSTS_VALU"],
                   "k_raster_salu_insts_per_launch": d["SQ_INSTS_SALU"], "k_raster_lds_insts_per_launch": d["SQ_INSTS_LDS"]})

@@ -130,7 +130,8 @@ typedef struct swr_render_pass {
     /* Scene identity (ABI 4).  The reference's only caller draws the SAME mesh every display frame with a new transform
      * (App.swift:153-185) and its GpuRenderer keeps its device buffers across calls (GpuRenderer.swift:32-33,41-67).
      * 0 = no promise: vertices / indices / attributes / texture are uploaded and the device-side triangle stream is
-     * rebuilt on every call (what ABI 3 did).  Non-zero = the caller promises that the CONTENT of `vertices`,
+     * rebuilt on every call (what ABI 3 did) — as a scene that lives for ONE frame: in index order (no Morton sort),
+     * built behind the copy of the index array.  Non-zero = the caller promises that the CONTENT of `vertices`,
      * `indices`, `attributes` and `texture` (and their counts / sizes) equals that of the last swr_render on this
      * context that carried the same id: the upload is then skipped and the pass costs one resident frame plus the
      * gather.  A new id (or new counts) uploads.  transform, flags, primitive_type, material and the image pointers

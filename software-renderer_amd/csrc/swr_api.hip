@@ -209,6 +209,7 @@ struct swr_context {
     } slot[NSLOT];
     hipStream_t bin_stream = nullptr;   // the stream binning is enqueued on (== stream when pipelining is off)
     hipStream_t bin_stream_own = nullptr;
+    hipEvent_t up_chunk_ev = nullptr;   // one-shot upload: index chunk k resident / its stream built
     uint64_t frame_no = 0;
     uint64_t synced_upto = 0;           // every frame below this has completed (full stream sync seen by the caller)
     int last_slot = 0;
@@ -903,8 +904,11 @@ int copy_band(swr_context* c, int fb, int img, void* dst_full, uint64_t frame) {
 int check_frames(swr_context* c);
 int enqueue_present(swr_context* c, void* color_full, float* depth_full);
 
+// oneshot: the scene is uploaded for ONE frame (swr_render without a scene identity, the reference's calling pattern):
+// the triangle stream keeps index order — the Morton sort costs more than it saves a single frame (cfg4: build 0.49 ->
+// 0.23 ms, the frame 0.154 -> 0.177 ms) — and it is built chunk by chunk behind the copy of the index array.
 int single_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vertex_count,
-                        const int64_t* indices, int64_t index_count) {
+                        const int64_t* indices, int64_t index_count, bool oneshot = false) {
     if (const int f = sticky(c)) return f;
     if (vertex_count < 0 || index_count < 0 || (index_count > 0 && (!indices || !vertices)))
         return fail(c, SWR_ERR_BAD_ARG, "swr_scene_upload: bad vertex/index arguments");
@@ -924,7 +928,7 @@ int single_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vert
     // SWR_SORT=0: keep index order (the original index still travels in GeomRec.flags);
     // SWR_SORT=-1: behave as for a scene of 2^24 primitives or more (no reordering, slot == index) — test hook
     static const int sort_mode = getenv("SWR_SORT") ? atoi(getenv("SWR_SORT")) : 1;
-    const bool reorder = sort_mode == 1 && ntri > 1 && ntri < SORT_MAX_TRIS;
+    const bool reorder = sort_mode == 1 && !oneshot && ntri > 1 && ntri < SORT_MAX_TRIS;
     const size_t sort_bytes = reorder ? stream_sort_temp_bytes(ntri) : 0;
     if ((rc = ensure(c, c->tri_xyz, (size_t)index_count * 16))) return rc;
     if ((rc = ensure(c, c->inv, (size_t)ntri * 4))) return rc;
@@ -943,22 +947,54 @@ int single_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vert
     if (vertex_count)
         HIP_TRY(c, hipMemcpyAsync(c->vertices.p, vertices, (size_t)vertex_count * sizeof(swr_vertex),
                                   hipMemcpyHostToDevice, c->stream));
-    if (index_count)
-        HIP_TRY(c, hipMemcpyAsync(c->indices.p, indices, (size_t)index_count * 8, hipMemcpyHostToDevice, c->stream));
-    HIP_TRY(c, hipEventRecord(c->up_ev[1], c->stream));
-    // index range check (Swift array subscript would trap, Renderer.swift:226)
-    HIP_TRY(c, hipMemsetAsync(c->slot[0].tilebuf.p, 0, CNT_WORDS * 4, c->stream));
-    launch_validate_indices((const int64_t*)c->indices.p, index_count, vertex_count, (uint32_t*)c->slot[0].tilebuf.p, c->stream);
-    HIP_TRY(c, hipGetLastError());
-    {
-        StreamBuild b{};
-        b.vertices = (const swr_vertex*)c->vertices.p; b.nv = vertex_count;
-        b.indices = (const int64_t*)c->indices.p; b.ntri = ntri;
-        b.sort = reorder;
-        b.scratch = (uint32_t*)c->stream_scratch.p;
-        b.sort_temp = c->sort_temp.p; b.sort_temp_bytes = sort_bytes;
-        b.tri_xyz = (float4*)c->tri_xyz.p; b.tri_rgb = (float4*)c->tri_rgb.p;
-        b.inv = (uint32_t*)c->inv.p; b.box64 = (float4*)c->box64.p;
+    StreamBuild b{};
+    b.vertices = (const swr_vertex*)c->vertices.p; b.nv = vertex_count;
+    b.indices = (const int64_t*)c->indices.p; b.ntri = ntri;
+    b.sort = reorder;
+    b.scratch = (uint32_t*)c->stream_scratch.p;
+    b.sort_temp = c->sort_temp.p; b.sort_temp_bytes = sort_bytes;
+    b.tri_xyz = (float4*)c->tri_xyz.p; b.tri_rgb = (float4*)c->tri_rgb.p;
+    b.inv = (uint32_t*)c->inv.p; b.box64 = (float4*)c->box64.p;
+    uint32_t* const bad = (uint32_t*)c->slot[0].tilebuf.p;     // CNT_BAD_INDEX lives in the first slot's counter words
+    HIP_TRY(c, hipMemsetAsync(bad, 0, CNT_WORDS * 4, c->stream));
+    // One-shot scenes with an index array worth cutting up (>= 4 MiB): the index check and the stream of chunk k run on
+    // the binning stream while chunk k+1 is on the link (a copy from pageable memory returns when its bytes are staged)
+    hipStream_t side = c->bin_stream_own && c->bin_stream_own != c->stream ? c->bin_stream_own : nullptr;
+    const char* const min_env = getenv("SWR_ONESHOT_MIN_TRIS");          // test hook: chunk small scenes too
+    const int64_t chunk_min = min_env ? std::max<int64_t>(64, atoll(min_env)) : (int64_t)1 << 18;
+    const bool chunked = oneshot && side && sort_mode != -1 && ntri >= chunk_min && ntri < SORT_MAX_TRIS;
+    if (chunked) {
+        // two chunks, the second one small: every extra copy call from pageable memory costs the link ~30 us, the last
+        // chunk's build is the tail (cfg4, whole call: {100} 3.10 ms, {70,100} 3.06, {50,82,100} 3.07, four quarters 3.12)
+#ifndef SWR_TUNE_ONESHOT_CUTS
+#define SWR_TUNE_ONESHOT_CUTS {70, 100}
+#endif
+        constexpr int cuts[] = SWR_TUNE_ONESHOT_CUTS;          // per cent of the primitives
+        if (!c->up_chunk_ev) HIP_TRY(c, hipEventCreateWithFlags(&c->up_chunk_ev, hipEventDisableTiming));
+        HIP_TRY(c, hipEventRecord(c->up_chunk_ev, c->stream));           // (vertices resident, counter words zero)
+        HIP_TRY(c, hipStreamWaitEvent(side, c->up_chunk_ev, 0));
+        int64_t t0 = 0;
+        for (const int cut : cuts) {
+            const int64_t t1 = cut >= 100 ? ntri : std::min(ntri, (ntri * cut / 100 + 63) / 64 * 64);
+            if (t1 <= t0) continue;
+            HIP_TRY(c, hipMemcpyAsync((int64_t*)c->indices.p + 3 * t0, indices + 3 * t0, (size_t)(t1 - t0) * 24, hipMemcpyHostToDevice, c->stream));
+            HIP_TRY(c, hipEventRecord(c->up_chunk_ev, c->stream));
+            HIP_TRY(c, hipStreamWaitEvent(side, c->up_chunk_ev, 0));
+            launch_validate_indices((const int64_t*)c->indices.p + 3 * t0, 3 * (t1 - t0), vertex_count, bad, side);
+            HIP_TRY(c, launch_build_stream_range(b, t0, t1, side));
+            t0 = t1;
+        }
+        HIP_TRY(c, hipEventRecord(c->up_ev[1], c->stream));
+        HIP_TRY(c, hipEventRecord(c->up_chunk_ev, side));
+        HIP_TRY(c, hipStreamWaitEvent(c->stream, c->up_chunk_ev, 0));
+        c->reordered = true;                                          // (identity order; the original index travels in GeomRec.flags)
+    } else {
+        if (index_count)
+            HIP_TRY(c, hipMemcpyAsync(c->indices.p, indices, (size_t)index_count * 8, hipMemcpyHostToDevice, c->stream));
+        HIP_TRY(c, hipEventRecord(c->up_ev[1], c->stream));
+        // index range check (Swift array subscript would trap, Renderer.swift:226)
+        launch_validate_indices((const int64_t*)c->indices.p, index_count, vertex_count, bad, c->stream);
+        HIP_TRY(c, hipGetLastError());
         HIP_TRY(c, launch_build_stream(b, c->stream));
         c->reordered = ntri > 0 && ntri < SORT_MAX_TRIS && sort_mode != -1;   // original index travels in GeomRec.flags
     }
@@ -1307,6 +1343,7 @@ void destroy_single(swr_context* c) {
         for (int r = 0; r < swr_context::RING; r++)
             for (int i = 0; i < 5; i++) hipEventDestroy(c->ev[r][i]);
     for (auto& e : c->up_ev) if (e) hipEventDestroy(e);
+    if (c->up_chunk_ev) hipEventDestroy(c->up_chunk_ev);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1735,7 +1772,13 @@ int swr_render(swr_context* c, const swr_render_pass* p) {
     c->rt.scene_cached = cached ? 1 : 0;
     if (!cached) {
         c->scene_id = 0;
-        if ((rc = swr_scene_upload(c, p->vertices, p->vertex_count, p->indices, p->index_count))) return rc;
+        // no identity = the scene lives for this frame only: uploaded in index order, built behind the copy
+        const bool oneshot = p->scene_id == 0;
+        if (is_group(c))
+            rc = group_run(c, [=](swr_context* k) { return single_scene_upload(k, p->vertices, p->vertex_count, p->indices, p->index_count, oneshot); });
+        else
+            rc = single_scene_upload(c, p->vertices, p->vertex_count, p->indices, p->index_count, oneshot);
+        if (rc) return rc;
         if (p->attributes && (rc = swr_scene_attributes(c, p->attributes, p->vertex_count))) return rc;
         if (p->texture && (rc = swr_texture_upload(c, p->texture, p->tex_width, p->tex_height))) return rc;
         c->scene_id = p->scene_id; c->scene_nv = p->vertex_count; c->scene_ni = p->index_count;

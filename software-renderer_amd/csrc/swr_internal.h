@@ -124,6 +124,7 @@ struct StreamBuild {
 };
 size_t stream_sort_temp_bytes(int64_t ntri);
 hipError_t launch_build_stream(const StreamBuild& b, hipStream_t s);
+hipError_t launch_build_stream_range(const StreamBuild& b, int64_t t0, int64_t t1, hipStream_t s);   // index order, primitives [t0, t1)
 void launch_gather_attrs(const swr_vertex_attr* attrs, int64_t nv, const int64_t* indices, int64_t ntri,
                          const float4* tri_xyz, float4* tri_nrm, float4* tri_rgb, hipStream_t s);
 void launch_texture_to_float(const uint32_t* bgra, int64_t n, float4* out, hipStream_t s);

@@ -19,6 +19,7 @@
 // The sort itself is hipCUB's device radix sort (stable, so equal codes keep index order): it runs once
 // per scene, not per frame.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <hipcub/hipcub.hpp>
 #include <stdint.h>
 
@@ -111,13 +112,14 @@ __global__ void k_morton(const swr_vertex* __restrict__ vtx, int64_t nv, const i
 }
 
 // slot s <- original primitive perm[s]
+// (perm == NULL: identity order, slots [s0, ntri) only — the one-shot upload's chunks)
 __global__ void k_gather_stream(const swr_vertex* __restrict__ v, int64_t nv, const int64_t* __restrict__ idx,
-                                int64_t ntri, const uint32_t* __restrict__ perm, float4* __restrict__ tri_xyz,
+                                int64_t s0, int64_t ntri, const uint32_t* __restrict__ perm, float4* __restrict__ tri_xyz,
                                 float4* __restrict__ tri_rgb, uint32_t* __restrict__ inv) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     const float4* vp = reinterpret_cast<const float4*>(v);
-    for (int64_t s = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < ntri; s += stride) {
-        const uint32_t o = perm[s];
+    for (int64_t s = s0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; s < ntri; s += stride) {
+        const uint32_t o = perm ? perm[s] : (uint32_t)s;
         inv[o] = (uint32_t)s;
 #pragma unroll
         for (int k = 0; k < 3; k++) {
@@ -134,8 +136,8 @@ __global__ void k_gather_stream(const swr_vertex* __restrict__ v, int64_t nv, co
 
 // one wave per group of 64 slots: object-space box of their 192 vertices.  A non-finite coordinate
 // poisons the box with NaN, which the frame's cull test reads as "cannot be culled".
-__global__ void k_box64(const float4* __restrict__ tri_xyz, int64_t ntri, float4* __restrict__ box64) {
-    const int64_t g = (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
+__global__ void k_box64(const float4* __restrict__ tri_xyz, int64_t g0, int64_t ntri, float4* __restrict__ box64) {
+    const int64_t g = g0 + (int64_t)blockIdx.x * (blockDim.x / 64) + (threadIdx.x >> 6);
     const int64_t groups = (ntri + 63) / 64;
     if (g >= groups) return;
     const int64_t s = g * 64 + (threadIdx.x & 63);
@@ -218,10 +220,22 @@ hipError_t launch_build_stream(const StreamBuild& b, hipStream_t s) {
         if (e != hipSuccess) return e;
         perm = ids_out;
     }
-    hipLaunchKernelGGL(k_gather_stream, dim3(2048), dim3(256), 0, s, b.vertices, b.nv, b.indices, b.ntri, perm,
+    hipLaunchKernelGGL(k_gather_stream, dim3(2048), dim3(256), 0, s, b.vertices, b.nv, b.indices, (int64_t)0, b.ntri, perm,
                        b.tri_xyz, b.tri_rgb, b.inv);
     const int64_t groups = (b.ntri + 63) / 64;
-    hipLaunchKernelGGL(k_box64, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, s, b.tri_xyz, b.ntri, b.box64);
+    hipLaunchKernelGGL(k_box64, dim3((unsigned)((groups + 3) / 4)), dim3(256), 0, s, b.tri_xyz, (int64_t)0, b.ntri, b.box64);
+    return hipGetLastError();
+}
+
+// The triangle stream of primitives [t0, t1) in index order (t0 a multiple of 64): what launch_build_stream does with
+// sort == false, for one chunk of the index array — the one-shot upload runs it behind each chunk's copy.
+hipError_t launch_build_stream_range(const StreamBuild& b, int64_t t0, int64_t t1, hipStream_t s) {
+    if (t1 <= t0) return hipSuccess;
+    const int64_t n = t1 - t0;
+    hipLaunchKernelGGL(k_gather_stream, dim3((unsigned)std::min<int64_t>(2048, (n + 255) / 256)), dim3(256), 0, s, b.vertices, b.nv,
+                       b.indices, t0, t1, (const uint32_t*)nullptr, b.tri_xyz, b.tri_rgb, b.inv);
+    const int64_t g0 = t0 / 64, g1 = (t1 + 63) / 64;
+    hipLaunchKernelGGL(k_box64, dim3((unsigned)((g1 - g0 + 3) / 4)), dim3(256), 0, s, b.tri_xyz, g0, t1, b.box64);
     return hipGetLastError();
 }
 

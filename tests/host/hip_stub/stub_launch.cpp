@@ -26,6 +26,7 @@ void launch_validate_indices(const int64_t* idx, int64_t n, int64_t nv, uint32_t
     fake_enqueue(s, [=] { for (int64_t i = 0; i < n; i++) if (idx[i] < 0 || idx[i] >= nv) counters[CNT_BAD_INDEX] = 1u; });
 }
 hipError_t launch_build_stream(const StreamBuild&, hipStream_t s) { fake_enqueue(s, nullptr); return hipSuccess; }
+hipError_t launch_build_stream_range(const StreamBuild&, int64_t, int64_t, hipStream_t s) { fake_enqueue(s, nullptr); return hipSuccess; }
 void launch_gather_attrs(const swr_vertex_attr*, int64_t, const int64_t*, int64_t, const float4*, float4*, float4*, hipStream_t s) { fake_enqueue(s, nullptr); }
 void launch_texture_to_float(const uint32_t*, int64_t, float4*, hipStream_t s) { fake_enqueue(s, nullptr); }
 

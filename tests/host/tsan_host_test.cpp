@@ -4,6 +4,7 @@
 // checked is ORDER (every host image shows the frame it was presented for), the error protocol, and that TSan stays silent.
 //   g++ -std=c++17 -O1 -g -fsanitize=thread -Itests/host/hip_stub -x c++ software-renderer_amd/csrc/swr_api.hip \
 //       tests/host/hip_stub/stub_runtime.cpp tests/host/hip_stub/stub_launch.cpp tests/host/tsan_host_test.cpp -lpthread
+#include <cstdlib>
 #include <atomic>
 #include <chrono>
 #include <cstdio>
@@ -81,6 +82,16 @@ static void resident(uint32_t devices) {
         CHECK(swr_render_timings(c, &rt) == SWR_OK && rt.scene_cached == (f > 0));
         CHECK(all_eq(img[2], (float)(4000 + f)));
     }
+    // ... and without one: the one-shot upload builds the stream on the binning stream, chunk by chunk behind the index copy
+    setenv("SWR_ONESHOT_MIN_TRIS", "64", 1);
+    rp.scene_id = 0; rp.index_count = 300;
+    for (int f = 0; f < 3; f++) {
+        tagm(rp.transform, (float)(5000 + f));
+        CHECK(swr_render(c, &rp) == SWR_OK);
+        CHECK(swr_render_timings(c, &rt) == SWR_OK && rt.scene_cached == 0);
+        CHECK(all_eq(img[2], (float)(5000 + f)));
+    }
+    unsetenv("SWR_ONESHOT_MIN_TRIS");
     // destroy with work in flight
     for (int f = 0; f < 40; f++) { tagm(m, 1.0f); swr_draw(c, m, SWR_FLAG_DEPTH_TEST | SWR_FLAG_NO_COLOR); if (f % 3 == 0) swr_present(c, nullptr, img[3]); }
     swr_context_destroy(c);

@@ -176,6 +176,41 @@ def test_scene_identity_skips_the_upload_and_zero_always_uploads(swr, oracle):
         assert np.array_equal(c, rc[0]) and d.tobytes() == rc[1].tobytes()
 
 
+@pytest.mark.parametrize("bands", [1, 3])
+def test_one_shot_scenes_are_built_behind_the_index_copy(swr, oracle, monkeypatch, bands):
+    """swr_render without a scene identity (the reference's calling pattern: GpuRenderer copies the arrays every call,
+    GpuRenderer.swift:41-67) uploads for ONE frame: index order, the triangle stream built chunk by chunk behind the copy of
+    the index array.  SWR_ONESHOT_MIN_TRIS lowers the size from which the array is cut up (default 2^18 primitives)."""
+    S = swr.scenes
+    monkeypatch.setenv("SWR_ONESHOT_MIN_TRIS", "64")
+    # an indexed mesh (shared vertices), primitive count not a multiple of the 64-slot groups or of the chunk size
+    torus = S.cfg2_teapot_scale()
+    keep = torus.indices[: 3 * 6001]
+    soup = S.random_soup(4999, 640, 360, 0xC0DE, r_ndc=0.06, flags=1, margin=1.05)
+    with swr.Context(0, device_count=bands if bands > 1 else 0) as ctx:
+        for v, i, m, w, h, fl in ((torus.vertices, keep, torus.transform, torus.width, torus.height, 1),
+                                  (soup.vertices, soup.indices, soup.transform, 640, 360, 1),
+                                  (soup.vertices, soup.indices, soup.transform, 640, 360, 0),
+                                  (soup.vertices, soup.indices, soup.transform, 640, 360, 1 | S.FLAG_METAL_RULES)):
+            c, d = ctx.render(v, i, m, w, h, fl, scene_id=0)
+            assert ctx.render_timings()["scene_cached"] == 0
+            if fl & S.FLAG_METAL_RULES:
+                rc, rd, _, _ = oracle.render_metal(v, i, m, w, h, 0)
+            else:
+                rc, rd, _, _ = oracle.render(v, i, m, w, h, fl | oracle.TINV_PER_TRIANGLE)
+            assert np.array_equal(c, rc) and d.tobytes() == rd.tobytes()
+        # a bad index in the LAST chunk is still reported (Swift's array subscript would trap, Renderer.swift:226)
+        bad = soup.indices.copy()
+        bad[-2] = soup.vertices.shape[0]
+        with pytest.raises(swr.SwrError) as e:
+            ctx.render(soup.vertices, bad, soup.transform, 640, 360, 1, scene_id=0)
+        assert e.value.code == -3                      # SWR_ERR_INDEX_RANGE
+        # ... and the context is fine afterwards; a scene WITH an identity is sorted as before and gives the same image
+        c, d = ctx.render(soup.vertices, soup.indices, soup.transform, 640, 360, 1, scene_id=0)
+        c2, d2 = ctx.render(soup.vertices, soup.indices, soup.transform, 640, 360, 1, scene_id=5)
+        assert np.array_equal(c, c2) and d.tobytes() == d2.tobytes()
+
+
 @pytest.mark.parametrize("fault", [1, 2])
 @pytest.mark.parametrize("bands", [1, 2])
 def test_a_wait_that_never_ends_fails_the_context_within_the_budget(swr, fault, bands):

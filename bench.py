@@ -354,7 +354,8 @@ def main():
             extra["swr_render_ms"] = cold["wall_ms"]
             extra["swr_render"] = {"cold": cold, "cached_scene": cached,
                                    "note": "one synchronous swr_render (medians).  cold: scene_id 0 = H2D of the 120 MB scene from pageable "
-                                           "arrays + index check / Morton sort / stream build + one frame + gather into page-locked images.  "
+                                           "arrays + the tail of the index check / stream build (index order, built behind the index copy) + one "
+                                           "frame + gather into page-locked images.  "
                                            "cached_scene: the same non-zero swr_render_pass.scene_id again = one resident frame + the gather "
                                            "(PCIe-bound).  h2d_ms from HIP events, the rest host wall clock"}
             depth_host.free()

@@ -1250,7 +1250,12 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
 #ifndef SWR_ROWSPLIT_MAX
 #define SWR_ROWSPLIT_MAX 128
 #endif
-    const bool rowsplit = m <= (uint32_t)SWR_ROWSPLIT_MAX;
+#ifndef SWR_ROWSPLIT_MAX_SPREAD
+#define SWR_ROWSPLIT_MAX_SPREAD 192
+#endif
+    // (up to 192 on grids that do not fill the chip — 1080p is 1 020 tiles: 20 000 triangles of ~100 px 70 -> 54 us, 300
+    // screen-filling ones 97 -> 80; cfg4's 4 080 tiles measured 1 % slower with it: profiles/r03/rowsplit_large_ab.txt)
+    const bool rowsplit = m <= (uint32_t)(gridDim.x <= 1536 ? SWR_ROWSPLIT_MAX_SPREAD : SWR_ROWSPLIT_MAX);
     const int WROWS = PROWS / (RASTER_THREADS / 64);
     const int Yw0 = rowsplit ? Yp0 + (tid >> 6) * WROWS : Yp0;          // this wave's rows of the tile
     const int Yw1 = rowsplit ? min(Yw0 + WROWS - 1, Yp1) : Yp1;
@@ -1319,7 +1324,11 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
             // the dense path below needs the exact small-coordinate arithmetic; everything else
             // (huge extents, large clipped area) is walked cooperatively in phase 2
             big = !t.ch.small || maxx - minx >= 16384 || (yb - ya + 1) * (bxb - bxa + 1) > BIG_AREA;
-            large = !big && (yb - ya + 1) * (bxb - bxa + 1) >= LARGE_AREA;
+            // "large" = half of what this WAVE walks of the tile (all of its rows, or its share of them when the waves split
+            // the rows): its spans are then about 32 pixels or more, the length the wide visits below are made for.  (Measured
+            // against half the TILE, a wave that walks 8 rows never saw a large triangle and sent 64-pixel spans through the
+            // ring 4 pixels at a time: 300 screen-filling triangles 252 us, 93 with this line.)
+            large = !big && (yb - ya + 1) * (bxb - bxa + 1) >= (LARGE_AREA / TILE_H) * (Yw1 - Yw0 + 1);
         }
 
         // A FEW large triangles among many small ones (a ground plane, a wall, an occluder: at most LARGE_MAX lanes of

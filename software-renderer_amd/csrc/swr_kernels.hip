@@ -1705,6 +1705,33 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
 #pragma unroll
         for (int g = 0; g < 8; g++) slots[(tid + (g >> 2) * RASTER_THREADS) * 4 + (g & 3)] = sl[g];
     }
+    // Depth-only z-tested frames: the depth IS the key's high word (min() keys: empty / +inf / NaN keys all decode to +inf), so
+    // the resolve is a decode and a store.  One exception: a depth of exactly zero — the key holds +0, the reference stores the
+    // sign its arithmetic produced (:257) — sends the wave through the general path below, which re-evaluates the winner.
+    if (ZTEST && !COLOR && VAR == 0) {
+        bool zero_seen = false;
+        for (int i = tid; i < TILE_W * TILE_H / 4; i += RASTER_THREADS) {
+            const int ly = (i * 4) / TILE_W, lx = (i * 4) % TILE_W;
+            const int y = Y0 + ly, x = X0 + lx;
+            if (y < Yp0 || y > Yp1 || x > X1) continue;
+            float d4[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t hi = (uint32_t)(keys[ly * TILE_W + lx + k] >> 32);
+                d4[k] = depth_from_orderable(min(hi, KEY_LIVE_BELOW));
+                zero_seen = zero_seen || (d4[k] == 0.0f);
+            }
+            const size_t at = (size_t)(y - a.tg.row_begin) * (size_t)W + (size_t)x;   // App.swift:351-360
+            if (vec_ok && x + 3 <= X1) {
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                f32x4 dv = {d4[0], d4[1], d4[2], d4[3]};
+                __builtin_nontemporal_store(dv, reinterpret_cast<f32x4*>(a.depth + at));
+            } else {
+                for (int k = 0; k < 4 && x + k <= X1; k++) a.depth[at + k] = d4[k];
+            }
+        }
+        if (!__any(zero_seen)) return;          // (wave-uniform; no barrier follows)
+    }
     // A thread's two 4-pixel groups are resolved TOGETHER, pixel by pixel: the record / colour gathers of a new winner
     // in group 0 and in group 1 are issued back to back and waited for once, so the chain a thread walks is four
     // gather latencies instead of eight (colour frames: the wait for those gathers, not the arithmetic, is what the

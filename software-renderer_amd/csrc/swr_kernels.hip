@@ -438,7 +438,15 @@ __device__ __forceinline__ void for_each_tile(const PixBox& b, uint32_t p, F&& f
         const uint32_t sp = (uint32_t)__builtin_amdgcn_readlane((int)p, src);
         const int stx0 = sb.x0 / TILE_W, sty0 = sb.y0 / TILE_H;
         const int sntx = sb.x1 / TILE_W - stx0 + 1, sn = sntx * (sb.y1 / TILE_H - sty0 + 1);
-        for (int k = lane; k < sn; k += 64) fn(sb, sp, stx0 + k % sntx, sty0 + k / sntx);
+        // lane k walks tiles k, k + 64, ...: (column, row) advance by (64 % sntx, 64 / sntx) with one carry — a screen-filling
+        // triangle is 64 steps of this loop in ONE wave, and the two divisions per step were most of each
+        const int dq = 64 / sntx, dr = 64 % sntx;
+        int cx = lane % sntx, cy = lane / sntx;
+        for (int k = lane; k < sn; k += 64) {
+            fn(sb, sp, stx0 + cx, sty0 + cy);
+            cx += dr; cy += dq;
+            if (cx >= sntx) { cx -= sntx; cy += 1; }
+        }
     }
 }
 

@@ -761,3 +761,16 @@ def test_soup_behind_an_occluder(gpu_ctx, oracle, swr, zocc, tilt, flags):
     # depth ties against the occluder: soup vertices snapped to the occluder's depth
     s.vertices[: s.vertices.shape[0] - 6 : 7, 2] = zocc
     check(gpu_ctx, oracle, s, flags)
+
+
+@pytest.mark.parametrize("ntri,w,h,r", [(60, 512, 512, 1.2), (100, 1920, 1080, 1.5), (150, 1280, 720, 0.9), (400, 1000, 500, 0.35)])
+def test_wide_visits_in_row_split_tiles(gpu_ctx, oracle, swr, ntri, w, h, r):
+    """Tiles with few, LARGE triangles: the waves split the tile's rows (<= 128 / 192 triangles per tile; four workgroups per
+    tile on grids of <= 320 tiles) AND the chunk takes the 32-pixel visits — 'large' is measured against the rows a wave
+    walks (the criterion the round's big-triangle regression came from).  Every rule set, colour and
+    depth-only."""
+    s = swr.scenes.random_soup(ntri, w, h, 0xB16 + ntri, r_ndc=r, flags=DT, margin=0.6)
+    for flags in (DT, DT | NC, 0):
+        check(gpu_ctx, oracle, s, flags)
+    check_metal(gpu_ctx, oracle, s)
+    check_metal(gpu_ctx, oracle, s, NC)

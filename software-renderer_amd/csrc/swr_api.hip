@@ -202,6 +202,7 @@ struct swr_context {
     // while k_raster of frame N runs on `stream` (HBM-bound vs LDS/VALU-bound: they overlap well).
     struct Slot {
         DevBuf geo, geo_full, ranges, bins, bin_matrix;
+        DevBuf biglist;        // fixed-stride bins: the frame's deferred large triangles (k_bin -> k_sort_bins)
         DevBuf live;           // per binning workgroup: count + surviving stream-group ids (k_setup_hist -> k_fill_lds)
         DevBuf tilebuf;        // [CNT_WORDS counters][tiles tile_count][tiles+1 tile_start][tiles cursor]
         hipEvent_t bin_done = nullptr, ras_done = nullptr;
@@ -531,6 +532,7 @@ DeviceFrame make_frame(swr_context* c, int si, uint64_t frame, const float m[16]
     f.host_counters = c->h_pairs_dev + (frame % swr_context::PAIR_RING);   // word CNT_PAIRS (= 0) of this frame
     f.host_max = c->h_pairs_dev + swr_context::PAIR_RING;                  // one word, overwritten by every frame
     f.skip_sort = 0;
+    f.defer_big = 0;
     f.tile_count = tb + CNT_WORDS;
     f.tile_start = tb + CNT_WORDS + tiles_of(c->tg);
     f.tile_cursor = tb + CNT_WORDS + 2 * tiles_of(c->tg) + 1;
@@ -560,6 +562,7 @@ DeviceFrame make_frame(swr_context* c, int si, uint64_t frame, const float m[16]
     f.fill = (uint32_t*)c->fillbuf[frame % swr_context::NFILL].p;
     f.fill_next = (uint32_t*)c->fillbuf[(frame + 1) % swr_context::NFILL].p;
     f.host_fill = c->h_pairs_dev + swr_context::PAIR_RING + 1 + (frame % swr_context::PAIR_RING);
+    f.biglist = (uint4*)sl.biglist.p;
     f.color = (uint8_t*)c->color[c->fb_cur].p;
     f.depth = (float*)c->depth[c->fb_cur].p;
     f.tg = c->tg;
@@ -679,7 +682,11 @@ int enqueue_frame(swr_context* c) {
     // the app's sphere 18.6 -> 17.1 us; -DSWR_TUNE_SORT_SPARSE=1 sorts always.)
     constexpr bool sort_sparse = SWR_TUNE_SORT_SPARSE != 0;
     // (a word the GPU overwrites while frames are in flight: read it as what it is, a relaxed atomic)
-    if (!sort_sparse && sort_stream_mode < 0 && __atomic_load_n(&c->h_pairs[swr_context::PAIR_RING], __ATOMIC_RELAXED) <= 128u) f.skip_sort = 1;
+    const uint32_t fullest = __atomic_load_n(&c->h_pairs[swr_context::PAIR_RING], __ATOMIC_RELAXED);
+    if (!sort_sparse && sort_stream_mode < 0 && fullest <= 128u) f.skip_sort = 1;
+    // bit 31 of that word: the latest rastered frame met triangles that cover hundreds of tiles — this frame's k_bin puts them on
+    // the deferred list and k_sort_bins appends them per tile (swr_kernels.hip, BIN_BIG_TILES); 0xFFFFFFFF = nothing known yet
+    f.defer_big = (fullest != 0xFFFFFFFFu && (fullest & 0x80000000u)) ? 1 : 0;
     const bool all = c->timing >= 2;
     if (f.ntri <= 0) { int rc = sync_streams(c); if (rc) return rc; pair_word(c, frame) = 0; }
     if (!f.fixed_bins) fill_word(c, frame) = 0;
@@ -939,6 +946,7 @@ int single_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vert
         if ((rc = ensure(c, sl.geo, (size_t)(index_count / 3) * sizeof(GeomRec)))) return rc;
         if ((rc = ensure(c, sl.geo_full, (size_t)(index_count / 3) * sizeof(GeomFull)))) return rc;
         if ((rc = ensure(c, sl.ranges, (size_t)(index_count / 3) * sizeof(uint2)))) return rc;
+        if ((rc = ensure(c, sl.biglist, (size_t)1024 * 16))) return rc;
         if ((rc = ensure(c, sl.live, (size_t)((index_count / 3 + 63) / 64 + 2 * 1024 + 2) * 4))) return rc;   // [G <= 1024][1 + per]
         if ((rc = ensure(c, sl.tilebuf, (size_t)(CNT_WORDS + 3 * std::max(1, tiles_of(c->tg)) + 1) * 4))) return rc;
     }
@@ -1322,7 +1330,7 @@ void destroy_single(swr_context* c) {
                       &c->fillbuf[0], &c->fillbuf[1], &c->fillbuf[2], &c->fillbuf[3]};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& sl : c->slot) {
-        DevBuf* sb[] = {&sl.geo, &sl.geo_full, &sl.ranges, &sl.bins, &sl.bin_matrix, &sl.live, &sl.tilebuf};
+        DevBuf* sb[] = {&sl.geo, &sl.geo_full, &sl.ranges, &sl.bins, &sl.bin_matrix, &sl.live, &sl.tilebuf, &sl.biglist};
         for (DevBuf* b : sb) if (b->p) hipFree(b->p);
         if (sl.bin_done) hipEventDestroy(sl.bin_done);
         if (sl.ras_done) hipEventDestroy(sl.ras_done);

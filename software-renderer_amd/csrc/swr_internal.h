@@ -87,6 +87,7 @@ struct DeviceFrame {
     uint32_t* counters;            // [CNT_WORDS]
     uint32_t* host_counters;       // device-visible address of the pinned host copy
     uint32_t* host_max;            // pinned host word: entries of the frame's fullest bin (written by k_fill_lds; may be NULL)
+    int32_t defer_big;             // 1: the previous frame had triangles for the deferred list (k_bin<DEFER>)
     int32_t skip_sort;             // 1: no k_sort_bins for this frame (every bin of the previous frames fitted two chunks)
     uint32_t* tile_cursor;         // [tiles] running fill position (starts as tile_start)
     uint2* ranges;                 // [ntri] band-clipped pixel bbox (x0|x1<<16, y0|y1<<16, y band-relative)
@@ -97,6 +98,7 @@ struct DeviceFrame {
     uint32_t* fill;                // [CNT_WORDS counters][tiles] of this frame, zero when k_bin starts
     uint32_t* fill_next;           // the next frame's block (k_bin zeroes it)
     uint32_t* host_fill;           // pinned host word: the frame's largest fill (overflow test)
+    uint4* biglist;                // [1024] triangles of the frame that cover too many tiles to be scattered by k_bin: k_sort_bins appends them per tile
     uint32_t* bin_matrix;          // [G][tiles] per-workgroup tile counts -> prefixes (LDS path)
     uint32_t* live;                // [G][1 + ceil(groups/G)] per binning workgroup: count + the stream groups that survived its cull
     int32_t live_parity;           // >= 0: cull the groups against the band; -1: every group is live

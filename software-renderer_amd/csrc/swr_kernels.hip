@@ -418,8 +418,11 @@ __device__ __forceinline__ uint32_t size_class(const PixBox& b, int tx, int ty) 
 // time, lanes striding over its tiles — a full-screen triangle would otherwise keep one lane busy
 // for thousands of iterations.  Must be called by all 64 lanes of the wave (b.x0 > b.x1 = no tiles).
 constexpr int COOP_TILES = 8;
-template <class F>
-__device__ __forceinline__ void for_each_tile(const PixBox& b, uint32_t p, F&& fn) {
+struct NoBigTiles { __device__ bool operator()(const PixBox&, uint32_t, int, int) const { return false; } };
+// big(box, p, owner lane, tiles): called once per triangle of more than COOP_TILES tiles, wave-uniformly; true = the caller has
+// taken care of it (k_bin's deferred list), it is not walked
+template <class F, class B = NoBigTiles>
+__device__ __forceinline__ void for_each_tile(const PixBox& b, uint32_t p, F&& fn, B&& big = NoBigTiles{}) {
     const bool any = b.x0 <= b.x1;
     const int tx0 = b.x0 / TILE_W, ty0 = b.y0 / TILE_H;
     const int ntx = any ? b.x1 / TILE_W - tx0 + 1 : 0, nty = any ? b.y1 / TILE_H - ty0 + 1 : 0;
@@ -438,6 +441,7 @@ __device__ __forceinline__ void for_each_tile(const PixBox& b, uint32_t p, F&& f
         const uint32_t sp = (uint32_t)__builtin_amdgcn_readlane((int)p, src);
         const int stx0 = sb.x0 / TILE_W, sty0 = sb.y0 / TILE_H;
         const int sntx = sb.x1 / TILE_W - stx0 + 1, sn = sntx * (sb.y1 / TILE_H - sty0 + 1);
+        if (big(sb, sp, src, sn)) continue;
         // lane k walks tiles k, k + 64, ...: (column, row) advance by (64 % sntx, 64 / sntx) with one carry — a screen-filling
         // triangle is 64 steps of this loop in ONE wave, and the two divisions per step were most of each
         const int dq = 64 / sntx, dr = 64 % sntx;
@@ -744,21 +748,43 @@ struct BinArgs {
     int per;                // stream groups owned by one workgroup
     int ntiles;
     int tag_class;
+    uint4* biglist;         // [BIGLIST_CAP] (slot, ranges.x, ranges.y, -) of the frame's deferred triangles
+    int defer_ok;           // this frame's k_sort_bins will run
 };
 constexpr uint32_t FIXED_CAP_MAX = 61440u;   // cursor halves stay below 2^16: cap + primitives owned by one workgroup < 65536
-enum { CNT_MAXFILL = 3 };
+enum { CNT_MAXFILL = 3, CNT_BIGLIST = 4, CNT_BIGSEEN = 5 };
+#ifndef SWR_TUNE_BIGLIST
+#define SWR_TUNE_BIGLIST 3          // bit 0: k_bin defers, bit 1: k_sort_bins appends (tuning builds)
+#endif
+#ifndef SWR_BL_KBIN
+#define SWR_BL_KBIN 1
+#define SWR_BL_SORT 1
+#define SWR_BL_RASTER 1
+#endif
+// Triangles that cover more than BIN_BIG_TILES tiles (a wall, a ground plane, an occluder: a screen-filling one is 4 080 tiles
+// at 4K) are not scattered into those tiles' bins by the wave that set them up — one 4-byte store per tile, each to another
+// cache line, from ONE compute unit: 300 screen-filling triangles at 1080p took k_bin 145 us that way — but put on a short list
+// (stream slot + box).  k_sort_bins, one workgroup per tile, appends the listed triangles that touch ITS tile to its own bin before
+// it sorts it: 1 020 workgroups write 113 entries each instead of five waves writing 23 000.  Only frames whose k_sort_bins runs
+// may defer (BinArgs::defer_ok); a full list, or a frame that skips the sort, bins them the old way.
+constexpr int BIN_BIG_TILES = 128;
+constexpr uint32_t BIGLIST_CAP = 1024u;
+__device__ __forceinline__ int tiles_of_box(const PixBox& b) {
+    return b.x0 <= b.x1 ? (b.x1 / TILE_W - b.x0 / TILE_W + 1) * (b.y1 / TILE_H - b.y0 / TILE_H + 1) : 0;
+}
 
-template <int BT, bool MT>
-__global__ __launch_bounds__(BT) void k_bin(BinArgs b) {
-    extern __shared__ uint32_t hist[];               // [(ntiles + 1) / 2] counters -> cursors, [per] surviving groups, [1] their count, [2 * BT / 64] reduction
+template <int BT, bool MT, bool DEFER>
+__global__ __launch_bounds__(BT) void k_bin(BinArgs b) {   // nine waves per SIMD = at most 56 VGPRs: one k_bin wave has to fit beside five raster waves of 88
+    extern __shared__ uint32_t hist[];               // [(ntiles + 1) / 2] counters -> cursors, [per] surviving groups, [1] their count, [2 * BT / 64] reduction, [1] deferred pairs
     const SetupArgs& a = b.a;
     const int ntiles = b.ntiles, per = b.per;
     const int hwords = (ntiles + 1) >> 1;
     uint32_t* mylist = hist + hwords;
     uint32_t& nlive_s = mylist[per];
     uint32_t* red = mylist + per + 1;
+    uint32_t& bigp_s = red[2 * (BT / 64)];           // (triangle, tile) pairs this workgroup handed to the deferred list
     const int t = threadIdx.x, lane = t & 63;
-    if (t == 0) nlive_s = 0u;
+    if (t == 0) { nlive_s = 0u; bigp_s = 0u; }
     for (int e = t; e < hwords; e += BT) hist[e] = 0u;
     {   // the next frame's counters and fill words
         uint32_t* fn = b.fill_next;
@@ -800,6 +826,14 @@ __global__ __launch_bounds__(BT) void k_bin(BinArgs b) {
             uint2 r = make_uint2(RANGE_NONE_X, 0u);
             if (p < a.ntri) {
                 r = setup_triangle_r<MT>(a, p, xa, xb, xc);
+                if (SWR_BL_KBIN && DEFER && tiles_of_box(unpack_box(r)) > BIN_BIG_TILES) {
+                    const uint32_t e = atomicAdd(&b.fill[CNT_BIGLIST], 1u);
+                    if (e < BIGLIST_CAP) {                           // (a full list: walked like any other)
+                        b.biglist[e] = make_uint4((uint32_t)p, r.x, r.y, 0u);
+                        atomicAdd(&bigp_s, (uint32_t)tiles_of_box(unpack_box(r)));   // k_sort_bins appends exactly these pairs
+                        r = make_uint2(RANGE_NONE_X, 0u);            // neither walk of this kernel sees it
+                    }
+                }
                 a.ranges[p] = r;
             }
             for_each_tile(unpack_box(r), (uint32_t)p, [&](const PixBox&, uint32_t, int tx, int ty) {
@@ -810,7 +844,7 @@ __global__ __launch_bounds__(BT) void k_bin(BinArgs b) {
     }
     __syncthreads();
     // ---- 3: reserve this workgroup's run in every tile region it touches
-    uint32_t psum = 0u, pmax = 0u;
+    uint32_t psum = t == 0 ? bigp_s : 0u, pmax = 0u;
     {
         uint32_t* fill = b.fill + CNT_WORDS;
         constexpr int U = 4;
@@ -880,6 +914,11 @@ __global__ __launch_bounds__(BT) void k_bin(BinArgs b) {
                 const uint32_t pos = (atomicAdd(&hist[tile >> 1], 1u << sh) >> sh) & 0xFFFFu;
                 if (pos < b.cap)
                     b.bins[(size_t)tile * b.cap + pos] = prim | (b.tag_class ? size_class(bx, tx, ty) << CLASS_SHIFT : 0u);
+            }, [&](const PixBox&, uint32_t, int, int sn) {
+                // a triangle for the deferred list, binned the plain way: tells the host to take the deferring kernel next time
+                // (here and not in the first walk, whose register budget it would break: 56, see above)
+                if (SWR_BL_KBIN && !DEFER && sn > BIN_BIG_TILES && lane == 0) atomicOr(&b.fill[CNT_BIGSEEN], 1u);
+                return false;
             });
         }
     }
@@ -965,13 +1004,45 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_bins(uint32_t* __restrict
                                                             const uint32_t* __restrict__ tile_start,
                                                             const uint32_t* __restrict__ counters,
                                                             uint32_t capacity, int tag_class,
-                                                            const uint32_t* __restrict__ fill, uint32_t fixed_cap) {
+                                                            uint32_t* __restrict__ fill, uint32_t fixed_cap,
+                                                            const uint4* __restrict__ biglist, int tiles_x) {
     __shared__ uint32_t cls_cnt[64];
+    __shared__ uint32_t app_count;
     const int tid = threadIdx.x;
     uint32_t b0, b1;
     if (fixed_cap) {        // fixed-stride bins (k_bin): tile t owns [t * cap, t * cap + fill[t])
         b0 = blockIdx.x * fixed_cap;
-        b1 = b0 + min(fill[CNT_WORDS + blockIdx.x], fixed_cap);
+        uint32_t count = fill[CNT_WORDS + blockIdx.x];
+        // the frame's deferred triangles (k_bin, BIN_BIG_TILES) that touch this tile join its bin here
+        const uint32_t nbig = (SWR_BL_SORT && biglist) ? min(fill[CNT_BIGLIST], BIGLIST_CAP) : 0u;     // workgroup-uniform
+        if (nbig) {
+            if (tid == 0) app_count = count;
+            __syncthreads();
+            const int tx = (int)blockIdx.x % tiles_x, ty = (int)blockIdx.x / tiles_x;
+            for (uint32_t base = 0; base < nbig; base += SORT_THREADS) {
+                const uint32_t e = base + (uint32_t)tid;
+                uint4 ent = make_uint4(0u, RANGE_NONE_X, 0u, 0u);
+                if (e < nbig) ent = biglist[e];
+                const PixBox bx = unpack_box(make_uint2(ent.y, ent.z));
+                const bool hit = bx.x0 <= bx.x1 && tx >= bx.x0 / TILE_W && tx <= bx.x1 / TILE_W &&
+                                 ty >= bx.y0 / TILE_H && ty <= bx.y1 / TILE_H;
+                const unsigned long long mask = __ballot(hit);
+                uint32_t wbase = 0u;
+                if ((tid & 63) == 0 && mask) wbase = atomicAdd(&app_count, (uint32_t)__popcll(mask));
+                wbase = (uint32_t)__builtin_amdgcn_readfirstlane((int)wbase);
+                if (hit) {
+                    const uint32_t pos = wbase + (uint32_t)__popcll(mask & ((1ull << (tid & 63)) - 1ull));
+                    if (pos < fixed_cap) bins[b0 + pos] = ent.x | (tag_class ? size_class(bx, tx, ty) << CLASS_SHIFT : 0u);
+                }
+            }
+            __syncthreads();
+            const uint32_t grown = app_count;
+            // (no frame-wide counter is touched here — thousands of workgroups on one word would serialise in the L2: k_bin
+            // has counted the deferred pairs, and k_raster bounds the fullest bin by k_bin's maximum + the length of the list)
+            if (tid == 0 && grown != count) fill[CNT_WORDS + blockIdx.x] = grown;
+            count = grown;
+        }
+        b1 = b0 + min(count, fixed_cap);
     } else {
         if (counters[CNT_PAIRS] > capacity) return;
         b0 = tile_start[blockIdx.x]; b1 = tile_start[blockIdx.x + 1];
@@ -1225,13 +1296,16 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
     // an overflowed frame (more pairs than the bins hold / a tile region too small) is rastered empty: the host grows the
     // bins and redraws it
     uint32_t b0 = 0u, b1 = 0u;
+    // the fullest bin of the frame, bounded: k_bin's maximum + the deferred triangles k_sort_bins may have appended to it
+    const uint32_t max_fill = a.fixed_cap ? a.fill[CNT_MAXFILL] + (SWR_BL_RASTER ? min(a.fill[CNT_BIGLIST], BIGLIST_CAP) : 0u) : 0u;
     if (a.fixed_cap && blockIdx.x == 0 && threadIdx.x == 0) {
         *a.host_pairs = a.fill[CNT_PAIRS];
-        *a.host_fill = a.fill[CNT_MAXFILL];
-        if (a.host_max) *a.host_max = a.fill[CNT_MAXFILL];
+        *a.host_fill = max_fill;
+        // (bit 31: the frame had triangles for the deferred list — the host then keeps k_sort_bins running, which is what appends them)
+        if (a.host_max) *a.host_max = a.fill[CNT_MAXFILL] | ((a.fill[CNT_BIGLIST] | a.fill[CNT_BIGSEEN]) ? 0x80000000u : 0u);
     }
     if (a.fixed_cap) {
-        if (a.fill[CNT_MAXFILL] <= a.fixed_cap) { b0 = (uint32_t)tile * a.fixed_cap; b1 = b0 + a.fill[CNT_WORDS + tile]; }
+        if (max_fill <= a.fixed_cap) { b0 = (uint32_t)tile * a.fixed_cap; b1 = b0 + a.fill[CNT_WORDS + tile]; }
     } else if (a.counters[CNT_PAIRS] <= a.capacity) {
         b0 = a.tile_start[tile]; b1 = a.tile_start[tile + 1];
     }
@@ -2047,8 +2121,10 @@ hipError_t prepare_device() {
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_bin<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_bin<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_bin<256, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_bin<256, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_bin<256, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)k_bin<256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     return hipFuncSetAttribute((const void*)k_fill_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -2106,9 +2182,17 @@ bool launch_bin(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     b.ntiles = f.tg.tiles_x * f.tg.tiles_y;
     b.per = live_groups_per_workgroup(f.ntri, f.plan.G);
     b.tag_class = f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0;
-    const size_t lds = (size_t)((b.ntiles + 1) / 2) * 4 + (size_t)(b.per + 1) * 4 + 2 * (256 / 64) * 4;
-    if (b.a.metal) SWR_LAUNCH(stop, (k_bin<256, true>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b);
-    else SWR_LAUNCH(stop, (k_bin<256, false>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b);
+    // the deferring kernel (three registers more: it would not fit beside five raster waves) only for frames
+    // whose predecessor reported triangles for the list, and whose k_sort_bins runs
+    b.biglist = f.biglist; b.defer_ok = ((SWR_TUNE_BIGLIST & 1) && f.biglist && f.defer_big && !f.skip_sort) ? 1 : 0;
+    const size_t lds = (size_t)((b.ntiles + 1) / 2) * 4 + (size_t)(b.per + 1) * 4 + 2 * (256 / 64) * 4 + 4;
+    if (b.defer_ok) {
+        if (b.a.metal) SWR_LAUNCH(stop, (k_bin<256, true, true>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b);
+        else SWR_LAUNCH(stop, (k_bin<256, false, true>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b);
+    } else {
+        if (b.a.metal) SWR_LAUNCH(stop, (k_bin<256, true, false>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b);
+        else SWR_LAUNCH(stop, (k_bin<256, false, false>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b);
+    }
     return stop != nullptr;
 }
 
@@ -2142,7 +2226,8 @@ bool launch_sort_bins(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     if (f.ntri <= 0 || tiles == 0 || f.skip_sort) return false;
     SWR_LAUNCH(stop, k_sort_bins, dim3(tiles), dim3(SORT_THREADS), 0, s, f.bins, (const uint32_t*)f.tile_start,
                (const uint32_t*)f.counters, f.capacity, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0,
-               (const uint32_t*)(f.fixed_bins ? f.fill : nullptr), f.fixed_bins ? f.cap_tile : 0u);
+               (uint32_t*)(f.fixed_bins ? f.fill : nullptr), f.fixed_bins ? f.cap_tile : 0u,
+               (const uint4*)((f.fixed_bins && (SWR_TUNE_BIGLIST & 2)) ? f.biglist : nullptr), (int)f.tg.tiles_x);
     return stop != nullptr;
 }
 

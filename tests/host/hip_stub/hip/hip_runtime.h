@@ -9,6 +9,7 @@
 
 struct float4 { float x, y, z, w; };
 struct uint2 { uint32_t x, y; };
+struct uint4 { uint32_t x, y, z, w; };
 struct int4 { int x, y, z, w; };
 static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
 

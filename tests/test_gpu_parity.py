@@ -774,3 +774,33 @@ def test_wide_visits_in_row_split_tiles(gpu_ctx, oracle, swr, ntri, w, h, r):
         check(gpu_ctx, oracle, s, flags)
     check_metal(gpu_ctx, oracle, s)
     check_metal(gpu_ctx, oracle, s, NC)
+
+
+def test_large_triangles_join_the_bins_at_the_sort(swr, oracle):
+    """Triangles that cover more than 128 tiles are not scattered into the bins by k_bin: from the second frame of a scene that
+    has them (the first one reports them to the host) they go on a list and k_sort_bins appends them per tile.
+    Several frames of one context, every rule set; a scene with more such triangles than the list holds (1 024: the rest is
+    binned the plain way)."""
+    S = swr.scenes
+    small = S.random_soup(20000, 1280, 720, 0x5A11, r_ndc=0.03, flags=DT, margin=1.05)
+    big = S.random_soup(40, 1280, 720, 0xB166, r_ndc=1.2, flags=DT, margin=0.8)
+    mixed = S.Scene("mixed", 1280, 720, np.concatenate([big.vertices, small.vertices]),
+                    np.concatenate([big.indices, small.indices + big.vertices.shape[0]]), S.identity(), DT)
+    many = S.random_soup(2200, 1280, 720, 0xB167, r_ndc=1.3, flags=DT, margin=0.4)      # ~1 300 of them cover > 128 tiles
+    for scene in (mixed, many):
+        with swr.Context() as ctx:
+            ctx.scene_upload(scene.vertices, scene.indices)
+            ctx.target_set(scene.width, scene.height)
+            for flags in (DT, DT | NC, 0, MR, DT):
+                if flags & MR:
+                    rc, rd, _, _ = oracle.render_metal(scene.vertices, scene.indices, scene.transform, scene.width, scene.height, 0)
+                else:
+                    rc, rd, _, _ = oracle.render(scene.vertices, scene.indices, scene.transform, scene.width, scene.height,
+                                                 flags | oracle.TINV_PER_TRIANGLE)
+                for frame in range(3):
+                    ctx.draw(scene.transform, flags)
+                    ctx.sync()
+                    d = ctx.read_depth()
+                    assert d.tobytes() == rd.tobytes(), f"{scene.name} flags={flags} frame {frame}: depth"
+                    if not (flags & NC):
+                        assert np.array_equal(ctx.read_color(), rc), f"{scene.name} flags={flags} frame {frame}: colour"

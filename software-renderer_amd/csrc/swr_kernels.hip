@@ -16,7 +16,8 @@
 //                                     with tile_start + matrix row, bins[ds_add_rtn(cursor)] = prim|class
 //                                     (no global atomics anywhere; k_setup_bin / k_scan / k_fill are the
 //                                     global-atomic fallback for tile tables that do not fit LDS)
-//   k_sort_bins   1 workgroup / tile: counting sort of the bin by size class (rows inside the tile)
+//   k_sort_bins   1 workgroup / tile: appends the frame's deferred triangles (k_bin: those that cover more than 128 tiles)
+//                                     that touch the tile, then counting sort of the bin by size class (rows inside the tile)
 //   k_raster      1 workgroup / tile: 64-bit visibility keys of the tile live in LDS.  Producer, lane =
 //                                     triangle: two integer edge steppers (a DDA of Renderer.interpolate) give
 //                                     the span of the lane's next row; ONE ring entry per span (owner lane, x,
@@ -26,7 +27,8 @@
 //                                     back into the ring.  Resolve: key -> winning primitive -> barycentric
 //                                     colour -> fragment_shader -> one 16-B/lane framebuffer store per
 //                                     4 pixels (clear fused: HBM sees each pixel exactly once).
-//   k_raster<.., METAL>             : the same frame under the Metal path's rules (SWR_FLAG_METAL_RULES)
+//   k_raster<.., METAL, COLOR>      : the same frame under the Metal path's rules (SWR_FLAG_METAL_RULES); colour and depth-only
+//                                     (SWR_FLAG_NO_COLOR) frames are separate kernels (own resolve, own register allocation)
 //   k_points / k_points_resolve     : PrimitiveType .vertices;  k_clear_band: .line (reference stub)
 //   k_raster<.., EXT>               : + the extended fragment stage at the resolve (normal / uv varyings,
 //                                     Blinn-Phong, bilinear texture; swr_shaders.hip.h)
@@ -753,14 +755,6 @@ struct BinArgs {
 };
 constexpr uint32_t FIXED_CAP_MAX = 61440u;   // cursor halves stay below 2^16: cap + primitives owned by one workgroup < 65536
 enum { CNT_MAXFILL = 3, CNT_BIGLIST = 4, CNT_BIGSEEN = 5 };
-#ifndef SWR_TUNE_BIGLIST
-#define SWR_TUNE_BIGLIST 3          // bit 0: k_bin defers, bit 1: k_sort_bins appends (tuning builds)
-#endif
-#ifndef SWR_BL_KBIN
-#define SWR_BL_KBIN 1
-#define SWR_BL_SORT 1
-#define SWR_BL_RASTER 1
-#endif
 // Triangles that cover more than BIN_BIG_TILES tiles (a wall, a ground plane, an occluder: a screen-filling one is 4 080 tiles
 // at 4K) are not scattered into those tiles' bins by the wave that set them up — one 4-byte store per tile, each to another
 // cache line, from ONE compute unit: 300 screen-filling triangles at 1080p took k_bin 145 us that way — but put on a short list
@@ -774,7 +768,9 @@ __device__ __forceinline__ int tiles_of_box(const PixBox& b) {
 }
 
 template <int BT, bool MT, bool DEFER>
-__global__ __launch_bounds__(BT) void k_bin(BinArgs b) {   // nine waves per SIMD = at most 56 VGPRs: one k_bin wave has to fit beside five raster waves of 88
+// Register budget of the plain kernel: 56 VGPRs (tools/vgprs.sh) — with 58 the pipelined cfg4 frame measured 4 % slower (one of its waves has
+// to fit beside five raster waves of 88); neither launch bounds nor amdgpu_waves_per_eu make this hipcc keep it, the source does.
+__global__ __launch_bounds__(BT) void k_bin(BinArgs b) {
     extern __shared__ uint32_t hist[];               // [(ntiles + 1) / 2] counters -> cursors, [per] surviving groups, [1] their count, [2 * BT / 64] reduction, [1] deferred pairs
     const SetupArgs& a = b.a;
     const int ntiles = b.ntiles, per = b.per;
@@ -826,7 +822,7 @@ __global__ __launch_bounds__(BT) void k_bin(BinArgs b) {   // nine waves per SIM
             uint2 r = make_uint2(RANGE_NONE_X, 0u);
             if (p < a.ntri) {
                 r = setup_triangle_r<MT>(a, p, xa, xb, xc);
-                if (SWR_BL_KBIN && DEFER && tiles_of_box(unpack_box(r)) > BIN_BIG_TILES) {
+                if (DEFER && tiles_of_box(unpack_box(r)) > BIN_BIG_TILES) {
                     const uint32_t e = atomicAdd(&b.fill[CNT_BIGLIST], 1u);
                     if (e < BIGLIST_CAP) {                           // (a full list: walked like any other)
                         b.biglist[e] = make_uint4((uint32_t)p, r.x, r.y, 0u);
@@ -917,7 +913,7 @@ __global__ __launch_bounds__(BT) void k_bin(BinArgs b) {   // nine waves per SIM
             }, [&](const PixBox&, uint32_t, int, int sn) {
                 // a triangle for the deferred list, binned the plain way: tells the host to take the deferring kernel next time
                 // (here and not in the first walk, whose register budget it would break: 56, see above)
-                if (SWR_BL_KBIN && !DEFER && sn > BIN_BIG_TILES && lane == 0) atomicOr(&b.fill[CNT_BIGSEEN], 1u);
+                if (!DEFER && sn > BIN_BIG_TILES && lane == 0) atomicOr(&b.fill[CNT_BIGSEEN], 1u);
                 return false;
             });
         }
@@ -1014,7 +1010,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_bins(uint32_t* __restrict
         b0 = blockIdx.x * fixed_cap;
         uint32_t count = fill[CNT_WORDS + blockIdx.x];
         // the frame's deferred triangles (k_bin, BIN_BIG_TILES) that touch this tile join its bin here
-        const uint32_t nbig = (SWR_BL_SORT && biglist) ? min(fill[CNT_BIGLIST], BIGLIST_CAP) : 0u;     // workgroup-uniform
+        const uint32_t nbig = biglist ? min(fill[CNT_BIGLIST], BIGLIST_CAP) : 0u;     // workgroup-uniform
         if (nbig) {
             if (tid == 0) app_count = count;
             __syncthreads();
@@ -1297,7 +1293,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
     // bins and redraws it
     uint32_t b0 = 0u, b1 = 0u;
     // the fullest bin of the frame, bounded: k_bin's maximum + the deferred triangles k_sort_bins may have appended to it
-    const uint32_t max_fill = a.fixed_cap ? a.fill[CNT_MAXFILL] + (SWR_BL_RASTER ? min(a.fill[CNT_BIGLIST], BIGLIST_CAP) : 0u) : 0u;
+    const uint32_t max_fill = a.fixed_cap ? a.fill[CNT_MAXFILL] + min(a.fill[CNT_BIGLIST], BIGLIST_CAP) : 0u;
     if (a.fixed_cap && blockIdx.x == 0 && threadIdx.x == 0) {
         *a.host_pairs = a.fill[CNT_PAIRS];
         *a.host_fill = max_fill;
@@ -2184,7 +2180,7 @@ bool launch_bin(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     b.tag_class = f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0;
     // the deferring kernel (three registers more: it would not fit beside five raster waves) only for frames
     // whose predecessor reported triangles for the list, and whose k_sort_bins runs
-    b.biglist = f.biglist; b.defer_ok = ((SWR_TUNE_BIGLIST & 1) && f.biglist && f.defer_big && !f.skip_sort) ? 1 : 0;
+    b.biglist = f.biglist; b.defer_ok = (f.biglist && f.defer_big && !f.skip_sort) ? 1 : 0;
     const size_t lds = (size_t)((b.ntiles + 1) / 2) * 4 + (size_t)(b.per + 1) * 4 + 2 * (256 / 64) * 4 + 4;
     if (b.defer_ok) {
         if (b.a.metal) SWR_LAUNCH(stop, (k_bin<256, true, true>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b);
@@ -2227,7 +2223,7 @@ bool launch_sort_bins(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     SWR_LAUNCH(stop, k_sort_bins, dim3(tiles), dim3(SORT_THREADS), 0, s, f.bins, (const uint32_t*)f.tile_start,
                (const uint32_t*)f.counters, f.capacity, f.ntri < (1ll << CLASS_SHIFT) ? 1 : 0,
                (uint32_t*)(f.fixed_bins ? f.fill : nullptr), f.fixed_bins ? f.cap_tile : 0u,
-               (const uint4*)((f.fixed_bins && (SWR_TUNE_BIGLIST & 2)) ? f.biglist : nullptr), (int)f.tg.tiles_x);
+               (const uint4*)(f.fixed_bins ? f.biglist : nullptr), (int)f.tg.tiles_x);
     return stop != nullptr;
 }
 

@@ -8,12 +8,13 @@ name = None
 for l in sys.stdin:
     m = re.search(r"Function Name: (\S+)", l)
     if m: name = m.group(1); row = {}
-    for k in ("VGPRs", "VGPRs Spill", "ScratchSize \[bytes/lane\]", "Occupancy \[waves/SIMD\]", "LDS Size \[bytes/block\]"):
-        m = re.search(r"\s" + k + r": (\d+)", l)
-        if m and name: row[k.split(" [")[0].replace("\\","")] = int(m.group(1))
+    for k, pat in (("VGPRs", r"\sVGPRs: (\d+)"), ("spill", r"VGPRs Spill: (\d+)"), ("scratch", r"ScratchSize \[bytes/lane\]: (\d+)"),
+                   ("waves", r"Occupancy \[waves/SIMD\]: (\d+)"), ("lds", r"LDS Size \[bytes/block\]: (\d+)")):
+        m = re.search(pat, l)
+        if m and name: row[k] = int(m.group(1))
     if name and "LDS Size" in l and ("k_raster" in name or "k_bin" in name):
         import subprocess
         d = subprocess.run(["c++filt", name], capture_output=True, text=True).stdout.strip().replace("swr::", "").replace("(swr::RasterArgs)", "")
-        print("%-44s VGPRs %3d  spill %2d  scratch %3d  waves/SIMD %d" % (d, row.get("VGPRs", -1), row.get("VGPRs Spill", 0), row.get("ScratchSize", 0), row.get("Occupancy", 0)))
+        print("%-50s VGPRs %3d  spill %2d  scratch %3d  waves/SIMD %d  static LDS %6d" % (d, row.get("VGPRs", -1), row.get("spill", 0), row.get("scratch", 0), row.get("waves", 0), row.get("lds", 0)))
 '
 rm -f /tmp/vgprs_$$.o

@@ -295,7 +295,7 @@ def main():
 
         if n_gpus == 1:
             # the same scene with the colour store on (8 B/pixel) — reported beside the headline
-            steps2 = max(args.steps // 4, 5)
+            steps2 = max(args.steps, 20)          # (a handful of frames would mostly time the pipeline filling up)
             dt2, _, _ = run(S.FLAG_DEPTH_TEST, steps2, 3, level=0)
             _, sums2, frames2 = run(S.FLAG_DEPTH_TEST, steps2, 2, level=1, sample=min(SAMPLE, 4))
             r2 = sums2["raster_ms"] / max(frames2, 1)

@@ -776,7 +776,8 @@ def test_wide_visits_in_row_split_tiles(gpu_ctx, oracle, swr, ntri, w, h, r):
     check_metal(gpu_ctx, oracle, s, NC)
 
 
-def test_large_triangles_join_the_bins_at_the_sort(swr, oracle):
+@pytest.mark.parametrize("bands", [1, 2])
+def test_large_triangles_join_the_bins_at_the_sort(swr, oracle, bands):
     """Triangles that cover more than 128 tiles are not scattered into the bins by k_bin: from the second frame of a scene that
     has them (the first one reports them to the host) they go on a list and k_sort_bins appends them per tile.
     Several frames of one context, every rule set; a scene with more such triangles than the list holds (1 024: the rest is
@@ -788,7 +789,7 @@ def test_large_triangles_join_the_bins_at_the_sort(swr, oracle):
                     np.concatenate([big.indices, small.indices + big.vertices.shape[0]]), S.identity(), DT)
     many = S.random_soup(2200, 1280, 720, 0xB167, r_ndc=1.3, flags=DT, margin=0.4)      # ~1 300 of them cover > 128 tiles
     for scene in (mixed, many):
-        with swr.Context() as ctx:
+        with swr.Context(0, device_count=bands if bands > 1 else 0) as ctx:      # (two bands: each sub-context has its own list)
             ctx.scene_upload(scene.vertices, scene.indices)
             ctx.target_set(scene.width, scene.height)
             for flags in (DT, DT | NC, 0, MR, DT):

@@ -1248,7 +1248,7 @@ __device__ __forceinline__ int wave_incl_add(int v) {
 #ifndef SWR_RASTER_VGPRS
 #define SWR_RASTER_VGPRS 88
 #endif
-template <bool ZTEST, int VAR, bool METAL, bool EXT, bool COLOR>
+template <bool ZTEST, int VAR, bool METAL, bool EXT, bool COLOR, int NGX = 0>
 __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
     static_assert(!METAL || ZTEST, "the Metal rules always z-test");
     static_assert(!EXT || COLOR, "the extended fragment stage only exists for colour frames");
@@ -1822,7 +1822,9 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
 #define SWR_NG_METAL_COLOR 2
 #define SWR_NG_EXT 1
 #endif
-    constexpr int NG = EXT ? SWR_NG_EXT : (!COLOR ? SWR_NG_DEPTH : (METAL ? SWR_NG_METAL_COLOR : SWR_NG_COLOR));
+    // (NGX != 0: the launch chose — colour frames of SPARSE scenes, whose binning is short, take the joint walk: cfg5 0.198 -> 0.186 ms,
+    // cfg3 0.0422 -> 0.0408; cfg4's colour frames, 245 triangles per tile, lose 7 % with it beside their long k_bin)
+    constexpr int NG = NGX ? NGX : (EXT ? SWR_NG_EXT : (!COLOR ? SWR_NG_DEPTH : (METAL ? SWR_NG_METAL_COLOR : SWR_NG_COLOR)));
     static_assert(NG == 1 || NG == 2, "a thread owns two groups");
     for (int i0 = tid; VAR != 8 && VAR != 10 && VAR != 11 && i0 < TILE_W * TILE_H / 4; i0 += NG * RASTER_THREADS) {
         int ly[NG], lx[NG], y[NG], x[NG];
@@ -1976,9 +1978,9 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
 // The kernels proper: the reference's fragment stage — colour and depth-only frames (SWR_FLAG_NO_COLOR) as separate kernels, so
 // that each has its own register allocation (tools/vgprs.sh: 86 depth-only, 91 colour, 88 Metal rules; the budget of 88 above is
 // the depth-only kernel's) — and the extended one (its resolve needs more).
-template <bool ZTEST, int VAR = 0, bool METAL = false, bool COLOR = false>
+template <bool ZTEST, int VAR = 0, bool METAL = false, bool COLOR = false, int NGX = 0>
 __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) __attribute__((amdgpu_num_vgpr(SWR_RASTER_VGPRS)))
-void k_raster(RasterArgs a) { raster_tile<ZTEST, VAR, METAL, false, COLOR>(a); }
+void k_raster(RasterArgs a) { raster_tile<ZTEST, VAR, METAL, false, COLOR, NGX>(a); }
 template <bool ZTEST, bool METAL = false>
 __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES_EXT)
 void k_raster_ext(RasterArgs a) { raster_tile<ZTEST, 0, METAL, true, true>(a); }
@@ -2284,7 +2286,11 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     }
 #endif
     if (f.flags & SWR_FLAG_DEPTH_TEST) {
-        if (a.color) SWR_LAUNCH(stop, (k_raster<true, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        // colour frames of sparse scenes (fewer than 64 primitives per tile on average: BASELINE configs 2, 3, 5) resolve their
+        // two groups together (raster_tile, NGX)
+        const bool sparse = f.ntri < (int64_t)64 * ntiles;
+        if (a.color && sparse) SWR_LAUNCH(stop, (k_raster<true, 0, false, true, 2>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        else if (a.color) SWR_LAUNCH(stop, (k_raster<true, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else SWR_LAUNCH(stop, (k_raster<true, 0, false, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
     } else {
         if (a.color) SWR_LAUNCH(stop, (k_raster<false, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);

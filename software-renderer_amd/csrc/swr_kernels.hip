@@ -1664,7 +1664,8 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
                         const float r0 = ta.y * dy, r1 = ta.w * dy;          // t01*dy, t11*dy
 #pragma unroll
                         for (int qq = 0; qq < UNIT; qq++) {
-                            const float dx = dx0 + (float)qq;                // exact: small integers
+                            // exact: small integers.  (dx0 is never -0, so + 0.0f is the identity: spelled out, the compiler must keep the add)
+                            const float dx = qq == 0 ? dx0 : dx0 + (float)qq;
                             const float w0 = ta.x * dx + r0;
                             const float w1 = ta.z * dx + r1;
                             const float w2 = 1.0f - w0 - w1;

@@ -317,3 +317,20 @@ def test_every_frame_of_an_unwaited_burst_is_intact_under_every_ordering_mode(sw
         same(imgs[k][0].array, imgs[k][1].array, rc_c, rc_d, f"burst frame {k} ({env or 'default'}, n={n})")
     for a, b in imgs:
         a.free(); b.free()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("bands", [2, 5])
+def test_full_size_one_shot_render_through_bands_equals_one_context(swr, bands):
+    """cfg4 at full size (1 M triangles, 4K) through swr_render WITHOUT a scene identity on a banded context: every band uploads
+    the scene for one frame (index order: nothing to cull by, exact-size bins) — the image equals the one a single context draws
+    from its sorted, resident scene, bit for bit (order-independent visibility keys)."""
+    sc = swr.scenes.cfg4_soup(depth_only=False)
+    with swr.Context() as one:
+        c_ref, d_ref = one.render(sc.vertices, sc.indices, sc.transform, sc.width, sc.height, 1, scene_id=5)
+    with swr.Context(0, device_count=bands) as grp:
+        c, d = grp.render(sc.vertices, sc.indices, sc.transform, sc.width, sc.height, 1, scene_id=0)
+        assert grp.render_timings()["scene_cached"] == 0
+        assert np.array_equal(c, c_ref) and d.tobytes() == d_ref.tobytes()
+        c, d = grp.render(sc.vertices, sc.indices, sc.transform, sc.width, sc.height, 1, scene_id=9)
+        assert np.array_equal(c, c_ref) and d.tobytes() == d_ref.tobytes()

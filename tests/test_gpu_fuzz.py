@@ -29,22 +29,29 @@ def one_case(swr, oracle, rng, case):
                     np.concatenate([b.indices, s.indices + b.vertices.shape[0]]), s.transform, DT)
     flags = int(rng.choice([DT, DT | NC, 0, NC, MR, MR | NC]))
     m = S.app_transform(float(rng.uniform(0, 6.28))) if rng.integers(0, 3) == 0 else s.transform
+    # the extended fragment stage (per-pixel Phong, textured) on a third of the colour frames
+    sh = None
+    if not (flags & NC) and rng.integers(0, 3) == 0:
+        sh = S.random_shading(s.vertices.shape[0], 0xFA00 + case, int(rng.choice([S.SHADER_PHONG, S.SHADER_TEXTURED_PHONG])),
+                              shininess_log2=int(rng.integers(0, 7)))
     if flags & MR:
-        rc, rd, _, err = oracle.render_metal(s.vertices, s.indices, m, w, h, flags & NC)
+        rc, rd, _, err = oracle.render_metal(s.vertices, s.indices, m, w, h, flags & NC, shading=sh)
     else:
-        rc, rd, _, err = oracle.render(s.vertices, s.indices, m, w, h, flags | oracle.TINV_PER_TRIANGLE)
+        rc, rd, _, err = oracle.render(s.vertices, s.indices, m, w, h, flags | oracle.TINV_PER_TRIANGLE, shading=sh)
     assert err == 0
     bands = int(rng.choice([0, 0, 2, 3]))
-    what = f"case {case}: {ntri} tris r={r:.3f} {w}x{h} flags={flags} bands={bands} kind={kind}"
+    what = f"case {case}: {ntri} tris r={r:.3f} {w}x{h} flags={flags} bands={bands} kind={kind} shader={None if sh is None else sh.shader}"
     with swr.Context(0, device_count=bands) as ctx:
         if rng.integers(0, 2):
-            c, d = ctx.render(s.vertices, s.indices, m, w, h, flags, scene_id=int(rng.choice([0, 17])))
+            c, d = ctx.render(s.vertices, s.indices, m, w, h, flags, shading=sh, scene_id=int(rng.choice([0, 17])))
             assert d.tobytes() == rd.tobytes(), what + " (render): depth"
             if not (flags & NC):
                 assert np.array_equal(c, rc), what + " (render): colour"
         else:
             ctx.scene_upload(s.vertices, s.indices)
             ctx.target_set(w, h)
+            if sh is not None:
+                ctx.shading_set(sh)
             for frame in range(3):                                  # (frames 2 and 3: sort heuristics and the deferred list settle)
                 ctx.draw(m, flags)
                 ctx.sync()

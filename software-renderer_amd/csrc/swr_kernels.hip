@@ -2294,7 +2294,8 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
         else if (a.color) SWR_LAUNCH(stop, (k_raster<true, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else SWR_LAUNCH(stop, (k_raster<true, 0, false, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
     } else {
-        if (a.color) SWR_LAUNCH(stop, (k_raster<false, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        if (a.color && f.ntri < (int64_t)64 * ntiles) SWR_LAUNCH(stop, (k_raster<false, 0, false, true, 2>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        else if (a.color) SWR_LAUNCH(stop, (k_raster<false, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else SWR_LAUNCH(stop, (k_raster<false, 0, false, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
     }
     return stop != nullptr;

@@ -18,6 +18,7 @@ NO_COLOR = 1 << 1
 INV_RCP = 1 << 8
 UNCLAMPED = 1 << 9
 TINV_PER_TRIANGLE = 1 << 10
+FMA_TRANSFORM = 1 << 11      # sensitivity switch, never the parity target
 
 
 class Stats(ctypes.Structure):
@@ -150,6 +151,20 @@ def render_metal(vertices, indices, transform, width: int, height: int, flags: i
                              v.ctypes.data, v.shape[0] if v.ndim == 2 else v.size // 8, i.ctypes.data, i.size,
                              m.ctypes.data, flags, row_begin, row_end, ctypes.byref(st))
     return color, depth, st, rc
+
+
+def project(vertices, transform, width, height, flags: int = 0):
+    """swro_project: screen x / y (before truncation) and NDC z of every vertex."""
+    v = np.ascontiguousarray(vertices, dtype=np.float32).reshape(-1, 8)
+    m = np.ascontiguousarray(transform, dtype=np.float32).reshape(16)
+    n = v.shape[0]
+    sx, sy, sz = (np.empty(n, np.float32) for _ in range(3))
+    L = lib()
+    L.swro_project.restype = None
+    L.swro_project.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64,
+                               ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+    L.swro_project(v.ctypes.data, n, m.ctypes.data, width, height, flags, sx.ctypes.data, sy.ctypes.data, sz.ctypes.data)
+    return sx, sy, sz
 
 
 def render_scene(scene, extra_flags: int = 0, **kw):

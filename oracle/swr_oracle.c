@@ -232,6 +232,42 @@ static void draw_triangle(frame_t* f, tri_t* t) {
     }
 }
 
+/* Vertex.apply(transform:) (Renderer.swift:159-163): xyzw = M * (x,y,z,1), accumulated column by column.
+ * Default: one rounding per multiply and per add (what -ffp-contract=off Swift / C gives).
+ * SWRO_FMA_TRANSFORM: the OTHER plausible lowering of Apple's closed simd_mul(float4x4, float4) on arm64 — fmul for
+ * the first column, then one fused multiply-add per further column (fmla) — used only to MEASURE how far that
+ * undetermined choice can move the image (tests/test_oracle.py::test_fma_transform_sensitivity_bound); the GPU path
+ * and every parity test use the default. */
+static void apply_transform(const float M[16], float x, float y, float z, uint32_t flags, float r[4]) {
+    for (int c = 0; c < 4; c++) {
+        float a = M[0 + c] * x;
+        if (flags & SWRO_FMA_TRANSFORM) {
+            a = fmaf(M[4 + c], y, a);
+            a = fmaf(M[8 + c], z, a);
+            a = fmaf(M[12 + c], 1.0f, a);
+        } else {
+            a = a + M[4 + c] * y;
+            a = a + M[8 + c] * z;
+            a = a + M[12 + c] * 1.0f;
+        }
+        r[c] = a;
+    }
+}
+
+/* The per-index vertex stage alone (Renderer.swift:159-171): screen x, y (fractional, before the truncation of :251)
+ * and NDC z of every vertex — for tests that compare transform variants vertex by vertex. */
+void swro_project(const swro_vertex* vertices, int64_t vertex_count, const float M[16], int64_t W, int64_t H,
+                  uint32_t flags, float* sx, float* sy, float* sz) {
+    const float fw = (float)W, fh = (float)H;
+    for (int64_t i = 0; i < vertex_count; i++) {
+        float r[4];
+        apply_transform(M, vertices[i].xyz[0], vertices[i].xyz[1], vertices[i].xyz[2], flags, r);
+        const float nx = r[0] / r[3], ny = r[1] / r[3], nz = r[2] / r[3];
+        const float u = nx * 0.5f + 0.5f, w = ny * -0.5f + 0.5f;
+        sx[i] = u * fw; sy[i] = w * fh; sz[i] = nz;
+    }
+}
+
 int swro_render(uint8_t* color, float* depth, int64_t W, int64_t H,
                 const swro_vertex* vertices, int64_t vertex_count,
                 const int64_t* indices, int64_t index_count,
@@ -267,13 +303,7 @@ int swro_render(uint8_t* color, float* depth, int64_t W, int64_t H,
              * column (col0*x, + col1*y, + col2*z, + col3*1); xyz / w */
             float x = v->xyz[0], y = v->xyz[1], z = v->xyz[2];
             float r[4];
-            for (int c = 0; c < 4; c++) {
-                float a = M[0 + c] * x;
-                a = a + M[4 + c] * y;
-                a = a + M[8 + c] * z;
-                a = a + M[12 + c] * 1.0f;
-                r[c] = a;
-            }
+            apply_transform(M, x, y, z, flags, r);
             float nx = r[0] / r[3], ny = r[1] / r[3], nz = r[2] / r[3];
             /* convertedToScreen (:165-171): uv = xy*(0.5,-0.5)+0.5 ; xy = uv*(W,H) (the
              * .rounded() at :168 applies to the (W,H) constant: a no-op) */
@@ -331,13 +361,7 @@ int swro_render_primitives(uint8_t* color, float* depth, int64_t W, int64_t H,
             const swro_vertex* v = &vertices[indices[i]];
             float x = v->xyz[0], y = v->xyz[1], z = v->xyz[2];
             float r[4];
-            for (int c = 0; c < 4; c++) {
-                float a = M[0 + c] * x;
-                a = a + M[4 + c] * y;
-                a = a + M[8 + c] * z;
-                a = a + M[12 + c] * 1.0f;
-                r[c] = a;
-            }
+            apply_transform(M, x, y, z, flags, r);
             float nx = r[0] / r[3], ny = r[1] / r[3];
             float sx = (nx * 0.5f + 0.5f) * fw;                   /* convertedToScreen :165-171 */
             float sy = (ny * -0.5f + 0.5f) * fh;

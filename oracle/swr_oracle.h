@@ -32,8 +32,11 @@ enum {
     SWRO_INV_RCP    = 1u << 8,  /* 2x2 inverse as adj * (1/det) instead of adj / det */
     SWRO_UNCLAMPED  = 1u << 9,  /* iterate rows/pixels exactly as Renderer.swift:275-283 does
                                    (off-screen included) and reject per pixel (:246-250) */
-    SWRO_TINV_PER_TRIANGLE = 1u << 10 /* hoist T() out of the pixel loop (same values; the
+    SWRO_TINV_PER_TRIANGLE = 1u << 10, /* hoist T() out of the pixel loop (same values; the
                                    reference recomputes it per pixel, Renderer.swift:251-252) */
+    SWRO_FMA_TRANSFORM = 1u << 11 /* Vertex.apply (Renderer.swift:160) with fused multiply-adds after the first
+                                   column — the other plausible arm64 lowering of Apple's simd_mul; a sensitivity
+                                   switch, never the parity target */
 };
 
 typedef struct swro_stats {
@@ -51,6 +54,10 @@ int swro_render(uint8_t* color, float* depth, int64_t W, int64_t H,
                 const int64_t* indices, int64_t index_count,
                 const float transform[16], uint32_t flags,
                 int64_t row_begin, int64_t row_end, swro_stats* stats);
+
+/* Vertex stage alone: screen x / y (before truncation) and NDC z of every vertex (flags: SWRO_FMA_TRANSFORM). */
+void swro_project(const swro_vertex* vertices, int64_t vertex_count, const float transform[16], int64_t W, int64_t H,
+                  uint32_t flags, float* sx, float* sy, float* sz);
 
 /* Same, with RenderPass.primitiveType (Renderer.swift:174-189, :210-219):
  *   0 = .triangle  -> swro_render

@@ -238,6 +238,11 @@ struct swr_context {
     uint32_t* h_pairs_dev = nullptr;
     bool frame_presented[PAIR_RING] = {};   // was frame f copied to the host (swr_present)?  Only then can an overflow be seen
     uint32_t* h_misc = nullptr;
+    // Depth-only z-tested frames: 32-bit depth keys (k_raster_depth) until the scene shows that too many of its tiles have
+    // to be rastered again with the 64-bit keys (depths that are not > +0: a 2-D scene at z = 0, geometry in front of the
+    // near plane); word 2 PAIR_RING + 1 of h_pairs receives the sampled count of such tiles, one launch late.
+    bool k32_ok = true;                 // reset by a new scene / target
+    DevBuf redo_cnt;                    // the device counter behind that word
     uint64_t frames_checked = 0;        // frames [frames_checked, frame_no) have not had their pair total looked at
     // Two host threads per context: every frame is ~9 HIP calls (3.5 us each); the binning stream's share (slot wait,
     // three or four launches, event record) is enqueued by `bin_worker` while the caller's thread enqueues the raster
@@ -477,6 +482,14 @@ int size_bins(swr_context* c) {
     if (!c->has_scene || !c->has_target) return SWR_OK;
     const int tiles = tiles_of(c->tg);
     const int64_t ntri = c->ni / 3;
+    {   // a new scene / target starts on the 32-bit depth keys again (swr_context::k32_ok)
+        int rc0 = ensure(c, c->redo_cnt, 16);
+        if (rc0) return rc0;
+        HIP_TRY(c, hipMemsetAsync(c->redo_cnt.p, 0, 16, c->stream));
+        if ((rc0 = wait_stream(c, c->stream, "raster stream (redo counter)"))) return sticky(c) ? sticky(c) : rc0;
+        c->h_pairs[2 * swr_context::PAIR_RING + 1] = 0u;
+        c->k32_ok = true;
+    }
     const char* bm = getenv("SWR_BIN_MODE");                  // "exact": the four-kernel path with exact-size bins (tests, tools)
     // A band of a large scene (what one GPU of N renders, §7) bins faster with round 2's chain of three short kernels than
     // with the one long k_bin, which shares the chip with the band's raster worse: worst band of N = 2 / 4 / 8 on one GPU
@@ -533,6 +546,9 @@ DeviceFrame make_frame(swr_context* c, int si, uint64_t frame, const float m[16]
     f.host_max = c->h_pairs_dev + swr_context::PAIR_RING;                  // one word, overwritten by every frame
     f.skip_sort = 0;
     f.defer_big = 0;
+    f.redo_dev = (uint32_t*)c->redo_cnt.p;
+    f.host_redo = c->h_pairs_dev + 2 * swr_context::PAIR_RING + 1;
+    f.k32 = (c->k32_ok && f.redo_dev) ? 1 : 0;
     f.tile_count = tb + CNT_WORDS;
     f.tile_start = tb + CNT_WORDS + tiles_of(c->tg);
     f.tile_cursor = tb + CNT_WORDS + 2 * tiles_of(c->tg) + 1;
@@ -687,6 +703,12 @@ int enqueue_frame(swr_context* c) {
     // bit 31 of that word: the latest rastered frame met triangles that cover hundreds of tiles — this frame's k_bin puts them on
     // the deferred list and k_sort_bins appends them per tile (swr_kernels.hip, BIN_BIG_TILES); 0xFFFFFFFF = nothing known yet
     f.defer_big = (fullest != 0xFFFFFFFFu && (fullest & 0x80000000u)) ? 1 : 0;
+    // 32-bit depth keys: one tile in REDO_SAMPLE (8) reports when it had to be rastered again (~6x the time of a tile that did
+    // not); from 2 % of the tiles on the 64-bit kernel is the cheaper one for this scene
+    if (f.k32) {
+        const uint32_t redo = __atomic_load_n(&c->h_pairs[2 * swr_context::PAIR_RING + 1], __ATOMIC_RELAXED);
+        if ((uint64_t)redo * 8u * 50u > (uint64_t)tiles_of(c->tg)) { c->k32_ok = false; f.k32 = 0; }
+    }
     const bool all = c->timing >= 2;
     if (f.ntri <= 0) { int rc = sync_streams(c); if (rc) return rc; pair_word(c, frame) = 0; }
     if (!f.fixed_bins) fill_word(c, frame) = 0;
@@ -1325,7 +1347,7 @@ void destroy_single(swr_context* c) {
                         "event record+wait %.2f | raster-stream launches %.2f | record(ras_done) %.2f\n", c->device,
                 (unsigned long long)c->hp_frames, c->hp_t[0] / c->hp_frames, c->hp_t[1] / c->hp_frames, c->hp_t[2] / c->hp_frames,
                 c->hp_t[3] / c->hp_frames, c->hp_t[4] / c->hp_frames, c->hp_t[5] / c->hp_frames);
-    DevBuf* bufs[] = {&c->vertices, &c->indices, &c->tri_rgb, &c->tri_xyz, &c->inv, &c->box64, &c->stream_scratch, &c->sort_temp,
+    DevBuf* bufs[] = {&c->redo_cnt, &c->vertices, &c->indices, &c->tri_rgb, &c->tri_xyz, &c->inv, &c->box64, &c->stream_scratch, &c->sort_temp,
                       &c->attrs, &c->tri_nrm, &c->texture, &c->texture_bytes, &c->color[0], &c->color[1], &c->depth[0], &c->depth[1],
                       &c->fillbuf[0], &c->fillbuf[1], &c->fillbuf[2], &c->fillbuf[3]};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
@@ -1369,14 +1391,14 @@ int create_single(int dev, swr_context** out, int helpers, uint32_t wait_budget_
         (e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->copy_stream[0], hipStreamNonBlocking)) != hipSuccess ||
         (e = hipStreamCreateWithFlags(&c->copy_stream[1], hipStreamNonBlocking)) != hipSuccess ||
-        (e = hipHostMalloc((void**)&c->h_pairs, (2 * swr_context::PAIR_RING + 1) * 4, hipHostMallocMapped)) != hipSuccess ||
+        (e = hipHostMalloc((void**)&c->h_pairs, (2 * swr_context::PAIR_RING + 2) * 4, hipHostMallocMapped)) != hipSuccess ||
         (e = hipHostGetDevicePointer((void**)&c->h_pairs_dev, c->h_pairs, 0)) != hipSuccess ||
         (e = hipHostMalloc((void**)&c->h_misc, CNT_WORDS * 4, hipHostMallocDefault)) != hipSuccess) {
         int rc = fail(nullptr, SWR_ERR_HIP, "context init on device %d failed: %s", dev, hipGetErrorString(e));
         destroy_single(c);
         return rc;
     }
-    memset(c->h_pairs, 0, (2 * swr_context::PAIR_RING + 1) * 4);
+    memset(c->h_pairs, 0, (2 * swr_context::PAIR_RING + 2) * 4);
     c->h_pairs[swr_context::PAIR_RING] = 0xFFFFFFFFu;     // fullest bin: unknown
     memset(c->h_misc, 0, CNT_WORDS * 4);
     {

@@ -87,6 +87,9 @@ struct DeviceFrame {
     uint32_t* counters;            // [CNT_WORDS]
     uint32_t* host_counters;       // device-visible address of the pinned host copy
     uint32_t* host_max;            // pinned host word: entries of the frame's fullest bin (written by k_fill_lds; may be NULL)
+    int32_t k32;                   // 1: depth-only z-tested frames take the 32-bit depth keys (k_raster_depth)
+    uint32_t* redo_dev;            // device word: tiles k_raster_depth had to raster again (sampled)
+    uint32_t* host_redo;           // pinned host word that receives it one launch later
     int32_t defer_big;             // 1: the previous frame had triangles for the deferred list (k_bin<DEFER>)
     int32_t skip_sort;             // 1: no k_sort_bins for this frame (every bin of the previous frames fitted two chunks)
     uint32_t* tile_cursor;         // [tiles] running fill position (starts as tile_start)

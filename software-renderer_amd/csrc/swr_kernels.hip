@@ -1102,7 +1102,58 @@ struct RasterArgs {
     uint32_t* host_fill;    // test) and the same for the host's sort heuristic — k_bin leaves them in device counters
     uint32_t* host_max;
     int vs_log;         // 2^vs_log workgroups per tile, each owning TILE_H >> vs_log of its rows (small grids, see launch_raster)
+    uint32_t* redo_dev; // k_raster_depth: tiles (one in REDO_SAMPLE) that had to be rastered again with 64-bit keys, since the last launch
+    uint32_t* host_redo;    // ... handed to the host's pinned word by the next launch (the host then switches the scene to the 64-bit kernel)
 };
+constexpr int REDO_SAMPLE = 8;
+
+// ---- LDS of one raster workgroup -------------------------------------------------------------------------------
+// 64-bit visibility keys (orderable depth << 32 | primitive, or ~primitive without z-test): every frame that needs the
+// winner's identity — colour frames, painter's order, the Metal rules.
+constexpr int RASTER_QCAP = 128;         // ring entries per wave (see raster_tile)
+struct alignas(16) RasterLds64 {
+    unsigned long long keys[TILE_W * TILE_H];
+    float4 tabAB[2 * RASTER_THREADS];    // per triangle of the batch: (t00, t01, t10, t11) | (za, zb, zc, (C.x - X0) | (C.y - Y0) << 16)
+    uint32_t tabP[RASTER_THREADS];       //                            original primitive index (the key's low word)
+    uint32_t queue[RASTER_THREADS / 64][RASTER_QCAP];
+    uint32_t next_chunk;                 // work-stealing cursor over the chunks of the sorted bin
+};
+// 32-bit keys: depth-only z-tested frames under the CPU rules (BASELINE config 4).  The image of such a frame is the
+// per-pixel minimum of the fragment depths (Renderer.swift:257-261); WHICH primitive wins a tie cannot be seen in it, except
+// through the sign of a zero (and never through anything else: equal non-zero floats have equal bits).  So the key is the
+// depth itself and the atomic an LDS float / integer minimum — no orderable map, no index word, half the LDS traffic — and
+// a tile whose result holds a value the 32-bit order cannot vouch for (below) is rastered again with the 64-bit keys.
+struct alignas(16) RasterLds32 {
+    float keys[TILE_W * TILE_H];
+    float4 tabAB[2 * RASTER_THREADS];
+    uint32_t tabP[4];                    // (unused: no index word)
+    uint32_t queue[RASTER_THREADS / 64][RASTER_QCAP];
+    uint32_t next_chunk;
+    uint32_t redo;                       // a thread of the resolve met a key the 64-bit path has to decide
+};
+// SWR_K32_INT = 1: ds_min_i32 on the raw float bits.  Exact for depths > +0 (positive floats, denormals included, order like
+// their bits; a positive NaN lies above +inf = the empty key and never wins; +inf never changes anything).  Any negative
+// int — a negative depth, -0, a negative NaN — beats every positive one, and +0 beats every positive depth, so a pixel
+// whose true minimum is not > +0 always ends with a key <= 0 (as int): the resolve sees it and the tile takes the 64-bit
+// path.  = 0: ds_min_f32 (tools/micro/ds_min_f32_semantics.hip records what the LDS does with NaN, -0 and denormals).
+#ifndef SWR_K32_INT
+#define SWR_K32_INT 1
+#endif
+__device__ __forceinline__ void k32_min(float* p, float d) {
+#if SWR_K32_INT
+    atomicMin(reinterpret_cast<int*>(p), __float_as_int(d));
+#else
+    __hip_atomic_fetch_min(p, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#endif
+}
+// does the resolve have to hand this tile to the 64-bit path?
+__device__ __forceinline__ bool k32_undecided(float k) {
+#if SWR_K32_INT
+    return __float_as_int(k) <= 0;
+#else
+    return !(k != 0.0f);                 // +-0 (the sign is the winner's, :257) or NaN
+#endif
+}
 
 constexpr unsigned long long KEY_EMPTY = ~0ull;
 // A pixel has a winner iff the high word of its key is below the orderable image of +inf: the z-mode dense step
@@ -1120,8 +1171,8 @@ struct TriState {
     uint32_t prim;
 };
 
-template <bool ZTEST>
-__device__ __forceinline__ void fragment(unsigned long long* keys, const TriState& t, int x, int lidx,
+template <bool ZTEST, class KeyT>
+__device__ __forceinline__ void fragment(KeyT* keys, const TriState& t, int x, int lidx,
                                          float r0, float r1) {
     // setPixel (:245-269): weights at the pixel centre (x+.5, y+.5) relative to cf
     unsigned long long key;
@@ -1133,12 +1184,13 @@ __device__ __forceinline__ void fragment(unsigned long long* keys, const TriStat
         const float w2 = 1.0f - w0 - w1;           // :92
         float d = t.za * w0 + t.zb * w1 + t.zc * w2;   // :257
         if (!(d < INFINITY)) return;               // can never pass 'depth < buffer' (:258); NaN too
+        if constexpr (std::is_same<KeyT, float>::value) { k32_min(&keys[lidx], d); return; }
         d = d + 0.0f;                              // -0 -> +0 for ordering only (== under '<')
         key = ((unsigned long long)orderable_depth(d) << 32) | (unsigned long long)t.prim;
     } else {
         key = (unsigned long long)(0xFFFFFFFFu - t.prim);   // painter's order: highest prim wins
     }
-    atomicMin(&keys[lidx], key);
+    if constexpr (!std::is_same<KeyT, float>::value) atomicMin(&keys[lidx], key);
 }
 
 __device__ __forceinline__ void load_tri(const GeomFull* __restrict__ full, uint32_t prim, const int4& q0,
@@ -1230,6 +1282,10 @@ __device__ __forceinline__ int wave_incl_add(int v) {
 // VAR > 0: timing-only ablations (results invalid), instantiated only under -DSWR_ABLATION (`make ablation`):
 //   1 = no LDS atomic, 2 = no per-pixel maths, 3 = producer only (no unit consumed), 4 = no row walk at all,
 //   8 = no resolve, 9 = no chunk at all, 10 = 4 + 8, 11 = 9 + 8 (tools/ablate.py)
+// VAR_ALLCOOP is not an ablation: every triangle takes the cooperative walk (lanes = pixels, one triangle at a time) and the
+// ring machinery is compiled out — the register-light, exact, ~6x slower way k_raster_depth re-rasters a tile whose 32-bit keys
+// could not decide it.
+constexpr int VAR_ALLCOOP = 20;
 #ifndef SWR_RASTER_MIN_WAVES_EXT
 #define SWR_RASTER_MIN_WAVES_EXT 4   // the extended fragment stage's resolve (normal, uv, texels) needs > 96 VGPRs
 #endif
@@ -1248,26 +1304,28 @@ __device__ __forceinline__ int wave_incl_add(int v) {
 #ifndef SWR_RASTER_VGPRS
 #define SWR_RASTER_VGPRS 88
 #endif
-template <bool ZTEST, int VAR, bool METAL, bool EXT, bool COLOR, int NGX = 0>
-__device__ __forceinline__ void raster_tile(const RasterArgs& a) {
+// K32: 32-bit depth keys (RasterLds32).  Returns true (workgroup-uniform) when the tile has to be rastered again with the
+// 64-bit keys — only a K32 instance ever does.
+template <bool ZTEST, int VAR, bool METAL, bool EXT, bool COLOR, int NGX = 0, bool K32 = false>
+__device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::conditional<K32, RasterLds32, RasterLds64>::type& L) {
     static_assert(!METAL || ZTEST, "the Metal rules always z-test");
     static_assert(!EXT || COLOR, "the extended fragment stage only exists for colour frames");
+    static_assert(!K32 || (ZTEST && !COLOR && !METAL), "32-bit keys: depth-only z-tested frames under the CPU rules");
 #ifndef SWR_UNIT
 #define SWR_UNIT 4
 #endif
     constexpr int UNIT = SWR_UNIT;    // consecutive pixels of one span handled by one lane of a dense step
 
-    __shared__ uint32_t next_chunk;           // work-stealing cursor over the chunks of the sorted bin
-    __shared__ float4 tabAB[2 * RASTER_THREADS];
-    float4* const tabA = tabAB;                    // per triangle of the batch: t00, t01, t10, t11
-    float4* const tabB = tabAB + RASTER_THREADS;   //                            za, zb, zc, (C.x - X0) | (C.y - Y0) << 16
-    uint32_t* const slots = reinterpret_cast<uint32_t*>(tabAB);   // resolve only (see below)
-    __shared__ uint32_t tabP[RASTER_THREADS]; //                            original primitive index (the key's low word)
+    uint32_t& next_chunk = L.next_chunk;           // work-stealing cursor over the chunks of the sorted bin
+    float4* const tabA = L.tabAB;                  // per triangle of the batch: t00, t01, t10, t11
+    float4* const tabB = L.tabAB + RASTER_THREADS; //                            za, zb, zc, (C.x - X0) | (C.y - Y0) << 16
+    uint32_t* const slots = reinterpret_cast<uint32_t*>(L.tabAB);   // resolve only (see below)
+    uint32_t* const tabP = L.tabP;                 //                            original primitive index (the key's low word)
     // per wave: ring of spans waiting for a lane.  entry = owner lane | xl << 6 | yl << 12 | (pixels - 1) << 17.
     // At most 63 entries wait when a producer step adds up to 64; a consumer step pops n and pushes back at most n.
-    constexpr int QCAP = 128;
-    __shared__ uint32_t queue[RASTER_THREADS / 64][QCAP];
-    __shared__ unsigned long long keys[TILE_W * TILE_H];
+    constexpr int QCAP = RASTER_QCAP;
+    auto& queue = L.queue;
+    auto* const keys = L.keys;
     // after the last chunk the per-triangle tables are dead: the resolve keeps the winners' stream slots there
     static_assert(sizeof(float4) * 2 * RASTER_THREADS >= sizeof(uint32_t) * TILE_W * TILE_H, "slots alias tabA + tabB");
     // (Early-z — sub-tile maxima of the keys, triangles dropped by a conservative depth bound over their clipped bounding
@@ -1287,7 +1345,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
     // rows of the tile this workgroup walks and resolves (the whole tile unless the grid is split, vs_log > 0)
     const int Yp0 = Y0 + part * PROWS;
     const int Yp1 = min(Yp0 + PROWS - 1, Y1);
-    if (Yp0 > Y1) return;     // the band ends above this slice (workgroup-uniform)
+    if (Yp0 > Y1) return false;     // the band ends above this slice (workgroup-uniform)
 
     // an overflowed frame (more pairs than the bins hold / a tile region too small) is rastered empty: the host grows the
     // bins and redraws it
@@ -1351,7 +1409,13 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
     }
 
     // clear fused into the LDS init (Renderer.clear :205-206, :232-236)
-    for (int i = tid; i < TILE_W * TILE_H; i += RASTER_THREADS) keys[i] = KEY_EMPTY;
+    if constexpr (K32) {
+        if (tid == 0) L.redo = 0u;
+        for (int i = tid; i < TILE_W * TILE_H / 4; i += RASTER_THREADS)
+            reinterpret_cast<float4*>(L.keys)[i] = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);   // (:206)
+    } else {
+        for (int i = tid; i < TILE_W * TILE_H; i += RASTER_THREADS) keys[i] = KEY_EMPTY;
+    }
     __syncthreads();
 
     while (VAR != 9 && VAR != 11 && chunk < nchunks) {
@@ -1418,6 +1482,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
             const unsigned long long lm = __ballot(have && large);
             if (lm != 0ull && __popcll(lm) <= LARGE_MAX) big = big || large;
         }
+        if (VAR == VAR_ALLCOOP) big = true;
         // ---- big or huge-coordinate triangles first, one at a time, walked by the whole wave ----
         // (done before the dense phase so that its per-triangle registers die early)
         unsigned long long bigmask = __ballot(have && big);
@@ -1447,8 +1512,9 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
                             float z = w0 * mt.z0 + w1 * mt.z1 + w2 * mt.z2;
                             if (z < INFINITY) {
                                 z = z + 0.0f;
-                                atomicMin(&keys[(y - Y0) * TILE_W + (x - X0)],
-                                          ((unsigned long long)orderable_depth(z) << 32) | (unsigned long long)uprim);
+                                if constexpr (!K32)
+                                    atomicMin(&keys[(y - Y0) * TILE_W + (x - X0)],
+                                              ((unsigned long long)orderable_depth(z) << 32) | (unsigned long long)uprim);
                             }
                         }
                     }
@@ -1548,7 +1614,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
                 tabB[tid] = make_float4(t.za, t.zb, t.zc,
                                         __int_as_float((int)(((uint32_t)(t.cx - X0) & 0xFFFFu) | ((uint32_t)(t.cy - Y0) << 16))));
             }
-            tabP[tid] = t.prim;
+            if (!K32) tabP[tid] = t.prim;
             int y = mine ? ya : 1;
             const int ye = mine ? yb : 0;
             uint32_t qhead = 0u, qcount = 0u;   // wave-uniform
@@ -1597,7 +1663,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
                 const int lidx00 = (int)((e >> 6) & 2047u) + off;                // yl * TILE_W + xl
                 const int xl00 = (int)((e >> 6) & 63u) + off, yl = (int)((e >> 12) & 31u);
                 const int nvalid0 = on ? min(len - off, UPX) : 0;
-                const uint32_t oprim = tabP[wbase + owner];
+                const uint32_t oprim = K32 ? 0u : tabP[wbase + owner];
                 float4 ta = make_float4(0, 0, 0, 0), tb = make_float4(0, 0, 0, 0);
                 if (ZTEST) { ta = tabA[wbase + owner]; tb = tabB[wbase + owner]; }
                 const int cp = __float_as_int(tb.w);
@@ -1655,7 +1721,26 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
                             d = d + 0.0f;
                             const unsigned long long key =
                                 ((unsigned long long)orderable_depth(d) << 32) | (unsigned long long)oprim;
-                            if (live) atomicMin(&keys[lidx0 + qq], key);
+                            if constexpr (!K32) { if (live) atomicMin(&keys[lidx0 + qq], key); }
+                        }
+                    } else if (K32) {
+                        // 32-bit keys: the depth is the key.  No -0 -> +0, no NaN / +inf clamp, no orderable map: a result the
+                        // plain order of the bits cannot vouch for sends the tile to the 64-bit path (k32_undecided, resolve)
+                        float dx0 = (float)dxi;                              // (x + .5) - cf.x, exact: small integers
+                        asm volatile("" : "+v"(dx0));
+                        const float dy = (float)dyi;                         // (y + .5) - cf.y
+                        const float r0 = ta.y * dy, r1 = ta.w * dy;          // t01*dy, t11*dy
+#pragma unroll
+                        for (int qq = 0; qq < UNIT; qq++) {
+                            const float dx = qq == 0 ? dx0 : dx0 + (float)qq;
+                            const float w0 = ta.x * dx + r0;
+                            const float w1 = ta.z * dx + r1;
+                            const float w2 = 1.0f - w0 - w1;
+                            float d = tb.x * w0 + tb.y * w1 + tb.z * w2;     // :257
+#if !SWR_K32_INT
+                            d = fminf(d, INFINITY);                          // NaN -> +inf (see tools/micro/ds_min_f32_semantics.hip)
+#endif
+                            if constexpr (K32) { if (qq < nvalid) k32_min(&keys[lidx0 + qq], d); }
                         }
                     } else if (ZTEST) {
                         float dx0 = (float)dxi;                              // (x + .5) - cf.x, exact: small integers
@@ -1677,13 +1762,13 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
                             const unsigned long long key =
                                 ((unsigned long long)orderable_depth(d) << 32) | (unsigned long long)oprim;
                             if (VAR == 1) { asm volatile("" ::"v"((uint32_t)key), "v"((uint32_t)(key >> 32))); continue; }
-                            if (qq < nvalid) atomicMin(&keys[lidx0 + qq], key);
+                            if constexpr (!K32) { if (qq < nvalid) atomicMin(&keys[lidx0 + qq], key); }
                         }
                     } else {
                         const unsigned long long key = (unsigned long long)(0xFFFFFFFFu - oprim);
 #pragma unroll
                         for (int qq = 0; qq < UNIT; qq++)
-                            if (qq < nvalid) atomicMin(&keys[lidx0 + qq], key);
+                            if constexpr (!K32) { if (qq < nvalid) atomicMin(&keys[lidx0 + qq], key); }
                     }
                 }   // sg
                 // the rest of a span longer than this visit goes back into the ring (behind everything that waits)
@@ -1748,7 +1833,9 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
             if (!stolen) steal_next();
             __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next chunk rewrites the tables
         };
-        {
+        if constexpr (VAR == VAR_ALLCOOP) {
+            steal_next();
+        } else {
             // wide mode when at least half of the chunk's triangles that take the dense route are large for this tile
             const unsigned long long dm = __ballot(have && !big);
             const unsigned long long lg = __ballot(have && !big && large);
@@ -1768,6 +1855,30 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
     constexpr bool want_color = COLOR;          // a.color != nullptr; depth-only frames (SWR_FLAG_NO_COLOR) have their own kernels
     const int W = a.tg.width;
     const bool vec_ok = (W & 3) == 0;
+    // 32-bit keys: the key is the depth (an untouched pixel still holds the +inf of the clear, :206); one 16-B LDS read and one
+    // 16-B store per four pixels.  A key that is not > +0 (k32_undecided) is one the 64-bit path has to decide.
+    if constexpr (K32) {
+        bool undecided = false;
+        for (int i = tid; i < TILE_W * TILE_H / 4; i += RASTER_THREADS) {
+            const int ly = (i * 4) / TILE_W, lx = (i * 4) % TILE_W;
+            const int y = Y0 + ly, x = X0 + lx;
+            if (y < Yp0 || y > Yp1 || x > X1) continue;
+            const float4 v = reinterpret_cast<const float4*>(L.keys)[i];
+            undecided = undecided || k32_undecided(v.x) || k32_undecided(v.y) || k32_undecided(v.z) || k32_undecided(v.w);
+            const size_t at = (size_t)(y - a.tg.row_begin) * (size_t)W + (size_t)x;   // App.swift:351-360
+            if (vec_ok && x + 3 <= X1) {
+                typedef float f32x4 __attribute__((ext_vector_type(4)));
+                f32x4 dv = {v.x, v.y, v.z, v.w};
+                __builtin_nontemporal_store(dv, reinterpret_cast<f32x4*>(a.depth + at));
+            } else {
+                const float d4[4] = {v.x, v.y, v.z, v.w};
+                for (int k = 0; k < 4 && x + k <= X1; k++) a.depth[at + k] = d4[k];
+            }
+        }
+        if (undecided) L.redo = 1u;
+        __syncthreads();
+        return L.redo != 0u;
+    } else {
     // Colour frames: the stream slots of ALL this thread's winners first (original index -> slot is a gather from a
     // 4 MB table; the keys hold the original index because it decides depth ties) — 8 independent loads in flight
     // instead of 4 + 4 behind each other — written back into the low words of the keys, which have done their job.
@@ -1787,7 +1898,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
     // Depth-only z-tested frames: the depth IS the key's high word (min() keys: empty / +inf / NaN keys all decode to +inf), so
     // the resolve is a decode and a store.  One exception: a depth of exactly zero — the key holds +0, the reference stores the
     // sign its arithmetic produced (:257) — sends the wave through the general path below, which re-evaluates the winner.
-    if (ZTEST && !COLOR && VAR == 0) {
+    if (ZTEST && !COLOR && (VAR == 0 || VAR == VAR_ALLCOOP)) {
         bool zero_seen = false;
         for (int i = tid; i < TILE_W * TILE_H / 4; i += RASTER_THREADS) {
             const int ly = (i * 4) / TILE_W, lx = (i * 4) % TILE_W;
@@ -1809,7 +1920,7 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
                 for (int k = 0; k < 4 && x + k <= X1; k++) a.depth[at + k] = d4[k];
             }
         }
-        if (!__any(zero_seen)) return;          // (wave-uniform; no barrier follows)
+        if (!__any(zero_seen)) return false;    // (wave-uniform; no barrier follows)
     }
     // A thread's two 4-pixel groups are resolved TOGETHER, pixel by pixel: the record / colour gathers of a new winner
     // in group 0 and in group 1 are issued back to back and waited for once, so the chain a thread walks is four
@@ -1974,6 +2085,8 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
             }
         }
     }
+    }   // !K32
+    return false;
 }
 
 // The kernels proper: the reference's fragment stage — colour and depth-only frames (SWR_FLAG_NO_COLOR) as separate kernels, so
@@ -1981,10 +2094,28 @@ __device__ __forceinline__ void raster_tile(const RasterArgs& a) {
 // the depth-only kernel's) — and the extended one (its resolve needs more).
 template <bool ZTEST, int VAR = 0, bool METAL = false, bool COLOR = false, int NGX = 0>
 __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) __attribute__((amdgpu_num_vgpr(SWR_RASTER_VGPRS)))
-void k_raster(RasterArgs a) { raster_tile<ZTEST, VAR, METAL, false, COLOR, NGX>(a); }
+void k_raster(RasterArgs a) {
+    __shared__ RasterLds64 L;
+    raster_tile<ZTEST, VAR, METAL, false, COLOR, NGX>(a, L);
+}
 template <bool ZTEST, bool METAL = false>
 __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES_EXT)
-void k_raster_ext(RasterArgs a) { raster_tile<ZTEST, 0, METAL, true, true>(a); }
+void k_raster_ext(RasterArgs a) {
+    __shared__ RasterLds64 L;
+    raster_tile<ZTEST, 0, METAL, true, true>(a, L);
+}
+// Depth-only z-tested frames under the CPU rules: 32-bit keys first; the rare tile whose result they cannot vouch for (a
+// depth that is not > +0) is rastered again, by the same workgroup, with the 64-bit keys.  One LDS block for both.
+__global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) __attribute__((amdgpu_num_vgpr(SWR_RASTER_VGPRS)))
+void k_raster_depth(RasterArgs a) {
+    constexpr size_t BYTES = sizeof(RasterLds64) > sizeof(RasterLds32) ? sizeof(RasterLds64) : sizeof(RasterLds32);
+    __shared__ __attribute__((aligned(16))) unsigned char raw[BYTES];
+    if (blockIdx.x == 0 && threadIdx.x == 0) *a.host_redo = atomicExch(a.redo_dev, 0u);     // what the launches before this one counted
+    if (raster_tile<true, 0, false, false, false, 0, true>(a, *reinterpret_cast<RasterLds32*>(raw))) {
+        if (threadIdx.x == 0 && blockIdx.x % REDO_SAMPLE == 0) atomicAdd(a.redo_dev, 1u);
+        raster_tile<true, VAR_ALLCOOP, false, false, false, 0, false>(a, *reinterpret_cast<RasterLds64*>(raw));
+    }
+}
 
 // ------------------------------------------------------------------------------------------
 // PrimitiveType .vertices (Renderer.swift:295-302) and .line (empty stub, :289-293)
@@ -2230,6 +2361,12 @@ bool launch_sort_bins(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     return stop != nullptr;
 }
 
+// (A/B and test hook: SWR_K32=0 keeps depth-only frames on the 64-bit keys)
+static bool raster_k32() {
+    static const bool on = !(getenv("SWR_K32") && getenv("SWR_K32")[0] == '0');
+    return on;
+}
+
 bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     RasterArgs a;
     a.geo = f.geo; a.geo_full = f.geo_full; a.tri_rgb = f.tri_rgb;
@@ -2248,6 +2385,7 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     a.fill = f.fixed_bins ? f.fill : nullptr;
     a.fixed_cap = f.fixed_bins ? f.cap_tile : 0u;
     a.host_pairs = f.host_counters; a.host_fill = f.host_fill; a.host_max = f.host_max;
+    a.redo_dev = f.redo_dev; a.host_redo = f.host_redo;
     const unsigned ntiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
     if (ntiles == 0) return false;
     // Small grids (a small window: the reference app's 512x512 is 128 tiles): four workgroups fit where one tile's
@@ -2292,6 +2430,7 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
         const bool sparse = f.ntri < (int64_t)64 * ntiles;
         if (a.color && sparse) SWR_LAUNCH(stop, (k_raster<true, 0, false, true, 2>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else if (a.color) SWR_LAUNCH(stop, (k_raster<true, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        else if (f.k32 && raster_k32()) SWR_LAUNCH(stop, k_raster_depth, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else SWR_LAUNCH(stop, (k_raster<true, 0, false, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
     } else {
         if (a.color && f.ntri < (int64_t)64 * ntiles) SWR_LAUNCH(stop, (k_raster<false, 0, false, true, 2>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);

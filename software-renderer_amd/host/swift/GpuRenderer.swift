@@ -1,6 +1,7 @@
 // GpuRenderer.swift — drop-in replacement body for renderer/GpuRenderer.swift:12-147.
 // Same class name, same `render(renderPass:)` signature (GpuRenderer.swift:35), same RenderPass /
-// Image / Vertex / Pixel types (they stay in the app's Renderer.swift:5-200 untouched).  Where the
+// Image / Vertex / Pixel types (declared in Renderer.swift of this directory, the replacement of the app's
+// Renderer.swift; with the app's own file kept they are the ones at Renderer.swift:5-200).  Where the
 // original builds MTLBuffers, encodes vertex_pass / roi_pass and one rasterizer_pass dispatch per
 // triangle and blocks twice in scheduleAndWait, this forwards the pass to libswr_hip.so.
 //

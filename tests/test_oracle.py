@@ -201,6 +201,46 @@ def test_inverse_variant_sensitivity_bound(oracle, swr):
     assert (diff.max(axis=-1) > 0).sum() < 1e-3 * st.fragments + 50
 
 
+def test_fma_transform_sensitivity_bound(oracle, swr):
+    """The second undetermined operation of the Apple-simd gap: does `matrix_float4x4 * float4`
+    (Renderer.swift:160) fuse its multiply-adds on arm64?  SWRO_FMA_TRANSFORM is the fmul + 3 x fmla lowering; the default
+    rounds every product and sum.  Measured here on BASELINE-shaped scenes, per vertex and per pixel:
+      * transforms whose entries are 0 / +-1 / powers of two in the rows that matter (cfg1, cfg4 — the headline workload —
+        and cfg5: identity) cannot tell the two apart at all: every product is exact;
+      * under the app's perspective transform (cfg2, cfg3: App.swift:169-183) 3-10 % of the screen coordinates and of the
+        NDC depths differ, by at most 2 ulp; that moves a TRUNCATED vertex (:251, :271 — the only way coverage could change)
+        with probability ~2 ulp x |coordinate| ~ 1e-4 per vertex: none in these scenes, asserted below as < 0.1 % of the
+        triangles; colour bytes: at most 1 LSB on < 0.1 % of the pixels (none here); stored depths: a few ulp."""
+    S = swr.scenes
+
+    def compare(sc):
+        a_c, a_d, st, rc = oracle.render_scene(sc)
+        b_c, b_d, _, rc2 = oracle.render_scene(sc, oracle.FMA_TRANSFORM)
+        assert rc == 0 and rc2 == 0
+        p0 = oracle.project(sc.vertices, sc.transform, sc.width, sc.height)
+        p1 = oracle.project(sc.vertices, sc.transform, sc.width, sc.height, oracle.FMA_TRANSFORM)
+        ulp = max(int(np.abs(a.view(np.int32).astype(np.int64) - b.view(np.int32).astype(np.int64)).max()) for a, b in zip(p0, p1))
+        moved = (np.trunc(p0[0]) != np.trunc(p1[0])) | (np.trunc(p0[1]) != np.trunc(p1[1]))
+        tri_moved = int(moved[np.asarray(sc.indices).reshape(-1, 3)].any(axis=1).sum())
+        diff = np.abs(a_c.astype(int) - b_c.astype(int))
+        both = np.isfinite(a_d) & np.isfinite(b_d)
+        d_ulp = np.abs(a_d.view(np.int32).astype(np.int64) - b_d.view(np.int32).astype(np.int64))[both]
+        return dict(ulp=ulp, tri_moved=tri_moved, tris=sc.triangles, px=int((diff.max(axis=-1) > 0).sum()), lsb=int(diff.max()),
+                    d_px=int((d_ulp > 0).sum()), d_ulp=int(d_ulp.max()) if d_ulp.size else 0, frags=st.fragments,
+                    empty_same=bool(np.array_equal(np.isfinite(a_d), np.isfinite(b_d))))
+
+    for sc in (S.cfg1_triangle(), S.cfg4_soup(ntri=30000, width=960, height=540, depth_only=False),
+               S.cfg5_sponza_scale(width=1920, height=1080, nx=128, ny=64)):
+        r = compare(sc)
+        assert r["ulp"] == 0 and r["px"] == 0 and r["d_px"] == 0, (sc.name, r)
+    for sc in (S.cfg2_teapot_scale(), S.cfg3_bunny_scale(width=960, height=540)):
+        r = compare(sc)
+        assert 0 < r["ulp"] <= 4, (sc.name, r)                     # measured: 2
+        assert r["tri_moved"] <= 1e-3 * r["tris"], (sc.name, r)      # measured: 0
+        assert r["lsb"] <= 1 and r["px"] <= 1e-3 * r["frags"] + 50, (sc.name, r)   # measured: 0 pixels
+        assert r["empty_same"] and r["d_ulp"] <= 64, (sc.name, r)   # coverage unchanged; stored depths a few ulp apart
+
+
 def test_band_rendering_assembles(oracle, swr):
     s = swr.scenes.random_soup(400, 128, 100, 21, r_ndc=0.2, flags=1)
     c, d, _, _ = oracle.render_scene(s)

@@ -4,13 +4,18 @@
 import ast, glob, json, os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = sys.argv[1], sys.argv[2]
-rnd = sys.argv[3] if len(sys.argv) > 3 else "r03"
+rnd = sys.argv[3] if len(sys.argv) > 3 else "r04"
 out = os.path.join(ROOT, "profiles", rnd)
 for f in glob.glob(os.path.join(ROOT, "gpurun_out", "refresh", src + "_*")):
     shutil.copy(f, os.path.join(out, dst + os.path.basename(f)[len(src):]))
-commit = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], text=True).strip()
+# the stamp is the commit that last changed the kernels, and only a committed build may be stamped: a measurement of
+# uncommitted kernel sources would carry the hash of different code
+dirty = subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "software-renderer_amd/csrc", "software-renderer_amd/Makefile"], text=True).strip()
+if dirty:
+    sys.exit("profiles_from_refresh: uncommitted changes under software-renderer_amd/csrc — commit the kernels, measure again, then stamp:\n" + dirty)
+commit = subprocess.check_output(["git", "-C", ROOT, "log", "-1", "--format=%h", "--", "software-renderer_amd/csrc", "software-renderer_amd/Makefile"], text=True).strip()
 raw = json.load(open(os.path.join(out, f"{dst}_traffic_raw_KB.json")))
-kr = next(k for k in raw if "k_raster<true, 0, false" in k)
+kr = next(k for k in raw if "k_raster_depth" in k or "k_raster<true, 0, false, false" in k)
 t = json.load(open(os.path.join(ROOT, "profiles", "traffic.json")))
 t.update({"commit": commit, "all_kernels_raw_KB": raw,
           "k_raster_fetch_bytes_raw": raw[kr]["FETCH_SIZE"] * 1024, "k_raster_write_bytes": raw[kr]["WRITE_SIZE"] * 1024,
@@ -18,7 +23,7 @@ t.update({"commit": commit, "all_kernels_raw_KB": raw,
 json.dump(t, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
 v = json.load(open(os.path.join(ROOT, "profiles", "valu.json")))
 for line in open(os.path.join(out, f"{dst}_sq_counters.txt")):
-    if "k_raster<true, 0, false" in line and "SQ_INSTS_VALU" in line:
+    if ("k_raster_depth" in line or "k_raster<true, 0, false, false" in line) and "SQ_INSTS_VALU" in line:
         d = ast.literal_eval(line[line.index("{"):])
         v.update({"commit": commit, "k_raster_valu_wave_insts_per_launch": d["SQ_INSTS_VALU"],
                   "k_raster_salu_insts_per_launch": d["SQ_INSTS_SALU"], "k_raster_lds_insts_per_launch": d["SQ_INSTS_LDS"]})

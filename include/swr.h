@@ -22,7 +22,7 @@
 extern "C" {
 #endif
 
-#define SWR_ABI_VERSION 4
+#define SWR_ABI_VERSION 5
 
 /* ---- status codes (the reference has no error channel: it fatalError()s / try!s,
  *      Renderer.swift:26,209,239,497; GpuRenderer.swift:20-31,37-38) ------------------ */
@@ -58,12 +58,22 @@ enum {
                                       Shaders.metal:158-165) */
     SWR_FLAG_NO_COLOR   = 1u << 1, /* depth-only pass: the colour image is neither cleared nor
                                       written (BASELINE config 4) */
-    SWR_FLAG_METAL_RULES = 1u << 2 /* the Metal path's rules instead of the CPU renderer's:
+    SWR_FLAG_METAL_RULES = 1u << 2, /* the Metal path's rules instead of the CPU renderer's:
                                       vertices snapped with round() (Shaders.metal:71), one thread per ROI
                                       pixel with inside = all(0 <= ws <= 1) (:133-153), z-test always on
                                       (:158-161), bgra8Unorm store (round to nearest), ROIs whose min-x or
                                       min-y is 0 skipped (GpuRenderer.swift:122-124); IEEE arithmetic (the
                                       reference's MTL_FAST_MATH build is not bit-reproducible) */
+    SWR_FLAG_REAL_LINES = 1u << 3  /* OPT-IN, .line primitives only.  Default (flag clear) = the reference as written:
+                                      draw(line:colorBuffer:depthBuffer:) has an empty body (Renderer.swift:289-293), a
+                                      .line pass only clears.  With the flag every 2-index primitive is drawn with the
+                                      reference's own DDA (draw(line:with:in:), Renderer.swift:405-419) between its two
+                                      transformed endpoints, truncated like .vertices does (:298-299): steps =
+                                      max(|dx|, |dy|), float x / y advanced by dx/steps, dy/steps, pixel
+                                      (Int(x.rounded()), Int(y.rounded())) for steps iterations (the end point itself is
+                                      not plotted), in the colour of the FIRST vertex, later primitives overwrite
+                                      earlier ones, no z-test, depth stays +inf.  Lines longer than 2^20 steps or with a
+                                      non-finite endpoint are skipped (the reference would trap / never finish) */
 };
 
 /* ---- Vertex (Renderer.swift:154-157): two SIMD3<Float>, each padded to 16 B --------- */
@@ -199,7 +209,8 @@ typedef struct swr_render_times {
     float gather_ms;        /* swr_present + swr_present_wait: bands -> the caller's images */
     float total_ms;
     int32_t scene_cached;
-    int32_t reserved;
+    int32_t frames;         /* frames the call drew: 1, or 2 when a tile overflowed its bin region and the frame was redrawn (ABI 5;
+                               was `reserved`) */
 } swr_render_times;
 int swr_render_timings(swr_context* ctx, swr_render_times* out);
 
@@ -209,6 +220,23 @@ int swr_render_timings(swr_context* ctx, swr_render_times* out);
  * Either way the context ends up failed (see swr_config.wait_budget_ms).  Never needed by a renderer. */
 enum { SWR_FAULT_NONE = 0, SWR_FAULT_LOST_EVENT = 1, SWR_FAULT_ENQUEUE = 2 };
 int swr_debug_fault(swr_context* ctx, int fault);
+
+/* Test hooks (ABI 5; until round 4 these were environment variables read by the product's hot-path setup): force a code
+ * path the library would otherwise choose by itself, for THIS context.  A hook takes effect at the next swr_scene_upload /
+ * swr_target_set / swr_render (the stream order, the bin layout, the one-shot threshold) or at the next frame (the others);
+ * results never depend on them — every parity test that sets one compares against the oracle.  Never needed by a renderer.
+ *   SWR_DEBUG_STREAM_ORDER      1 (default) Morton-ordered triangle stream; 0 keep the caller's primitive order;
+ *                               -1 behave as for scenes of >= 2^24 primitives (no reordering, slot == index)
+ *   SWR_DEBUG_CULL              1 (default) per-band culling of 64-primitive groups; 0 off
+ *   SWR_DEBUG_BIN_MODE          0 (default) chosen per scene / target; 1 exact-size bins (four-kernel chain);
+ *                               2 fixed-stride bins (k_bin) also for bands of large scenes; 3 global-atomic binning fallback
+ *   SWR_DEBUG_ONESHOT_MIN_TRIS  primitives from which a swr_render without a scene identity cuts its index copy in two
+ *                               (default 2^18; minimum 64)
+ *   SWR_DEBUG_DEPTH_KEYS32      1 (default) depth-only z-tested frames take 32-bit depth keys (k_raster_depth); 0 the 64-bit kernel
+ *   SWR_DEBUG_RASTER_SORT       1 (default) such frames sort their bins inside the raster workgroups; 0 k_sort_bins launch */
+enum { SWR_DEBUG_STREAM_ORDER = 1, SWR_DEBUG_CULL = 2, SWR_DEBUG_BIN_MODE = 3, SWR_DEBUG_ONESHOT_MIN_TRIS = 4,
+       SWR_DEBUG_DEPTH_KEYS32 = 5, SWR_DEBUG_RASTER_SORT = 6 };
+int swr_debug_set(swr_context* ctx, int key, int64_t value);
 
 /* Renderer.render(renderPass:) (Renderer.swift:204-230) and GpuRenderer.render(renderPass:)
  * (GpuRenderer.swift:35-90): caller-owned host memory in, colour + depth images filled on

@@ -15,6 +15,7 @@ _LIB_PATH = os.path.join(_HERE, "libswr_oracle.so")
 
 DEPTH_TEST = 1 << 0
 NO_COLOR = 1 << 1
+REAL_LINES = 1 << 3          # .line primitives: the DDA of Renderer.swift:405-419 instead of the empty stub
 INV_RCP = 1 << 8
 UNCLAMPED = 1 << 9
 TINV_PER_TRIANGLE = 1 << 10

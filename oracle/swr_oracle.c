@@ -331,6 +331,7 @@ int swro_render(uint8_t* color, float* depth, int64_t W, int64_t H,
 }
 
 /* Renderer.render with primitiveType .line / .vertices (Renderer.swift:210-229, :289-302). */
+#define SWRO_LINE_MAX_STEPS (1 << 20)   /* longer lines are skipped (documented deviation, include/swr.h SWR_FLAG_REAL_LINES) */
 int swro_render_primitives(uint8_t* color, float* depth, int64_t W, int64_t H,
                            const swro_vertex* vertices, int64_t vertex_count,
                            const int64_t* indices, int64_t index_count,
@@ -375,6 +376,47 @@ int swro_render_primitives(uint8_t* color, float* depth, int64_t W, int64_t H,
             p[1] = swro_quantise(v->color[1]);
             p[2] = swro_quantise(v->color[0]);
             p[3] = swro_quantise(1.0f);
+        }
+    }
+    if (primitive_type == 1 && (flags & SWRO_REAL_LINES) && !(flags & SWRO_NO_COLOR)) {
+        /* OPT-IN: the reference's own line DDA, draw(line:with:in:) (Renderer.swift:405-419), between the two transformed
+         * endpoints truncated like draw(vertices:) does (:298-299); colour of the first vertex; in index order. */
+        const float fw = (float)W, fh = (float)H;
+        for (int64_t l = 0; l < index_count / 2; l++) {
+            int64_t ex[2], ey[2];
+            int ok = 1;
+            for (int k = 0; k < 2; k++) {
+                const swro_vertex* v = &vertices[indices[2 * l + k]];
+                float r[4];
+                apply_transform(M, v->xyz[0], v->xyz[1], v->xyz[2], flags, r);
+                const float nx = r[0] / r[3], ny = r[1] / r[3];
+                const float sx = (nx * 0.5f + 0.5f) * fw, sy = (ny * -0.5f + 0.5f) * fh;
+                if (!(fabsf(sx) < COORD_LIMIT) || !(fabsf(sy) < COORD_LIMIT)) { ok = 0; break; }
+                ex[k] = (int64_t)sx; ey[k] = (int64_t)sy;
+            }
+            if (!ok) { st.triangles_skipped++; continue; }
+            const int64_t dx = ex[1] - ex[0], dy = ey[1] - ey[0];                       /* :406-407 */
+            const int64_t adx = dx < 0 ? -dx : dx, ady = dy < 0 ? -dy : dy;
+            const int64_t steps = adx > ady ? adx : ady;                                 /* :408 */
+            if (steps > SWRO_LINE_MAX_STEPS) { st.triangles_skipped++; continue; }
+            st.triangles_drawn++;
+            const float xs = (float)dx / (float)steps, ys = (float)dy / (float)steps;   /* :409-410 */
+            float x = (float)ex[0], y = (float)ey[0];                                   /* :412-413 */
+            const swro_vertex* va = &vertices[indices[2 * l]];
+            for (int64_t k = 0; k < steps; k++) {                                        /* :414 */
+                const int64_t px = (int64_t)roundf(x), py = (int64_t)roundf(y);         /* :415 rounded(): half away from zero */
+                if (px >= 0 && px < W && py >= row_begin && py < row_end) {              /* the setter drops OOB (:30-36) */
+                    st.fragments++;
+                    st.fragments_written++;
+                    uint8_t* p = color + (size_t)(py * W + px) * 4;
+                    p[0] = swro_quantise(va->color[2]);
+                    p[1] = swro_quantise(va->color[1]);
+                    p[2] = swro_quantise(va->color[0]);
+                    p[3] = swro_quantise(1.0f);
+                }
+                x += xs;                                                                 /* :416-417 */
+                y += ys;
+            }
         }
     }
     if (stats) *stats = st;

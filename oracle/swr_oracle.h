@@ -28,6 +28,8 @@ typedef struct swro_vertex {
 enum {
     SWRO_DEPTH_TEST = 1u << 0,  /* restore Renderer.swift:257-261 */
     SWRO_NO_COLOR   = 1u << 1,  /* depth-only: colour image untouched */
+    SWRO_REAL_LINES = 1u << 3,  /* swro_render_primitives, .line only: the DDA of Renderer.swift:405-419 between the two
+                                   truncated endpoints instead of the empty stub of :289-293 (= SWR_FLAG_REAL_LINES) */
     /* oracle-only switches */
     SWRO_INV_RCP    = 1u << 8,  /* 2x2 inverse as adj * (1/det) instead of adj / det */
     SWRO_UNCLAMPED  = 1u << 9,  /* iterate rows/pixels exactly as Renderer.swift:275-283 does

@@ -13,6 +13,7 @@ from .binding import (  # noqa: F401
     FLAG_DEPTH_TEST,
     FLAG_METAL_RULES,
     FLAG_NO_COLOR,
+    FLAG_REAL_LINES,
     Context,
     HostImage,
     SwrError,

@@ -14,6 +14,7 @@ _LIB = os.environ.get("SWR_LIBRARY") or os.path.join(_PKG, "lib", "libswr_hip.so
 FLAG_DEPTH_TEST = 1
 FLAG_NO_COLOR = 2
 FLAG_METAL_RULES = 4
+FLAG_REAL_LINES = 8      # .line primitives: the reference's DDA (Renderer.swift:405-419) instead of its empty stub (:289-293)
 
 # every symbol include/swr.h declares (checked by tests/test_abi.py)
 ABI_SYMBOLS = [
@@ -23,8 +24,11 @@ ABI_SYMBOLS = [
     "swr_band_rows", "swr_scene_attributes", "swr_material_set", "swr_texture_upload",
     "swr_timing_sample", "swr_context_bands", "swr_context_band_info", "swr_host_alloc", "swr_host_free",
     "swr_host_register", "swr_host_unregister", "swr_present", "swr_present_wait", "swr_device_count",
-    "swr_render_timings", "swr_debug_fault",
+    "swr_render_timings", "swr_debug_fault", "swr_debug_set",
 ]
+# swr_debug_set keys (test hooks, include/swr.h)
+DEBUG_STREAM_ORDER, DEBUG_CULL, DEBUG_BIN_MODE, DEBUG_ONESHOT_MIN_TRIS, DEBUG_DEPTH_KEYS32, DEBUG_RASTER_SORT = 1, 2, 3, 4, 5, 6
+BIN_MODE_AUTO, BIN_MODE_EXACT, BIN_MODE_FIXED, BIN_MODE_ATOMIC = 0, 1, 2, 3
 
 
 class SwrError(RuntimeError):
@@ -73,10 +77,10 @@ class RenderTimes(ctypes.Structure):
     """swr_render_times: wall-clock phases of the last swr_render."""
     _fields_ = [("h2d_ms", ctypes.c_float), ("stream_build_ms", ctypes.c_float), ("draw_ms", ctypes.c_float),
                 ("gather_ms", ctypes.c_float), ("total_ms", ctypes.c_float), ("scene_cached", ctypes.c_int32),
-                ("reserved", ctypes.c_int32)]
+                ("frames", ctypes.c_int32)]
 
     def as_dict(self):
-        return {k: getattr(self, k) for k, _ in self._fields_ if k != "reserved"}
+        return {k: getattr(self, k) for k, _ in self._fields_}
 
 FAULT_NONE, FAULT_LOST_EVENT, FAULT_ENQUEUE = 0, 1, 2
 
@@ -158,6 +162,8 @@ def load_library():
         L.swr_render_timings.restype = ctypes.c_int
         L.swr_debug_fault.argtypes = [vp, ctypes.c_int]
         L.swr_debug_fault.restype = ctypes.c_int
+        L.swr_debug_set.argtypes = [vp, ctypes.c_int, ctypes.c_int64]
+        L.swr_debug_set.restype = ctypes.c_int
     except AttributeError:
         if not os.environ.get("SWR_LIBRARY"):      # only an older A/B build loaded by tools/ may lack the ABI 4 entry points
             raise
@@ -371,6 +377,10 @@ class Context:
         t = RenderTimes()
         self._check(self._L.swr_render_timings(self._h, ctypes.byref(t)))
         return t.as_dict()
+
+    def debug_set(self, key: int, value: int):
+        """Test hooks (swr_debug_set): force a code path for this context; results never depend on them."""
+        self._check(self._L.swr_debug_set(self._h, int(key), ctypes.c_int64(int(value))))
 
     def debug_fault(self, fault: int):
         """Fault injection for the failure-path tests (FAULT_LOST_EVENT / FAULT_ENQUEUE)."""

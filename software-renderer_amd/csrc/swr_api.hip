@@ -134,6 +134,13 @@ struct swr_context {
     std::string failed_msg;
     uint32_t wait_budget_ms = 20000;
     std::atomic<int> inject{0};         // swr_debug_fault: consumed by the next frame's raster share
+    // swr_debug_set (test hooks; the defaults are what a renderer gets)
+    int dbg_stream_order = 1;           // 1 Morton-ordered stream, 0 caller's order, -1 as for >= 2^24 primitives
+    int dbg_cull = 1;                   // per-band culling of 64-primitive groups
+    int dbg_bin_mode = 0;               // 0 auto, 1 exact-size bins, 2 fixed-stride bins everywhere, 3 global-atomic fallback
+    int64_t dbg_oneshot_min_tris = (int64_t)1 << 18;
+    bool dbg_k32 = true;                // depth-only z-tested frames on 32-bit depth keys
+    bool dbg_insort = true;             // ... which sort their bins inside the raster workgroups
     // scene identity of swr_render (swr_render_pass.scene_id): what is resident
     uint64_t scene_id = 0;
     int64_t scene_nv = -1, scene_ni = -1;
@@ -241,7 +248,9 @@ struct swr_context {
     // Depth-only z-tested frames: 32-bit depth keys (k_raster_depth) until the scene shows that too many of its tiles have
     // to be rastered again with the 64-bit keys (depths that are not > +0: a 2-D scene at z = 0, geometry in front of the
     // near plane); word 2 PAIR_RING + 1 of h_pairs receives the sampled count of such tiles, one launch late.
-    bool k32_ok = true;                 // reset by a new scene / target
+    bool k32_ok = true;                 // reset by a scene of another size / another tile grid
+    int64_t sized_ntri = -1;            // what size_bins last sized the bins for
+    int sized_tiles = -1;
     DevBuf redo_cnt;                    // the device counter behind that word
     uint64_t frames_checked = 0;        // frames [frames_checked, frame_no) have not had their pair total looked at
     // Two host threads per context: every frame is ~9 HIP calls (3.5 us each); the binning stream's share (slot wait,
@@ -482,21 +491,21 @@ int size_bins(swr_context* c) {
     if (!c->has_scene || !c->has_target) return SWR_OK;
     const int tiles = tiles_of(c->tg);
     const int64_t ntri = c->ni / 3;
-    {   // a new scene / target starts on the 32-bit depth keys again (swr_context::k32_ok)
+    {   // the redo counter of the 32-bit depth keys starts from zero (swr_context::k32_ok is reset by the callers)
         int rc0 = ensure(c, c->redo_cnt, 16);
         if (rc0) return rc0;
         HIP_TRY(c, hipMemsetAsync(c->redo_cnt.p, 0, 16, c->stream));
         if ((rc0 = wait_stream(c, c->stream, "raster stream (redo counter)"))) return sticky(c) ? sticky(c) : rc0;
         c->h_pairs[2 * swr_context::PAIR_RING + 1] = 0u;
-        c->k32_ok = true;
+        c->sized_ntri = ntri; c->sized_tiles = tiles;
     }
-    const char* bm = getenv("SWR_BIN_MODE");                  // "exact": the four-kernel path with exact-size bins (tests, tools)
+
     // A band of a large scene (what one GPU of N renders, §7) bins faster with round 2's chain of three short kernels than
     // with the one long k_bin, which shares the chip with the band's raster worse: worst band of N = 2 / 4 / 8 on one GPU
     // 52.4 / 37.6 / 27.9 us per frame against 59.3 / 38-40 / 30.7 (profiles/r03/b_band_proxy_*); the whole 4K frame is
-    // the other way round (81.9 vs 84.0).  SWR_BIN_MODE=fixed forces k_bin.
-    const bool band_like = tiles < 3000 && ntri >= 200000 && !(bm && bm[0] == 'f');
-    const bool no_fixed = (bm && bm[0] == 'e') || band_like;
+    // the other way round (81.9 vs 84.0).  swr_debug_set(SWR_DEBUG_BIN_MODE, 2) forces k_bin.
+    const bool band_like = tiles < 3000 && ntri >= 200000 && c->dbg_bin_mode != 2;
+    const bool no_fixed = c->dbg_bin_mode == 1 || c->dbg_bin_mode == 3 || band_like;
     const uint32_t cmax = (c->fixed_allowed && !no_fixed) ? fixed_cap_max(ntri, tiles) : 0u;
     int rc;
     if (cmax) {
@@ -537,6 +546,7 @@ DeviceFrame make_frame(swr_context* c, int si, uint64_t frame, const float m[16]
     f.texels = (const float4*)c->texture.p;
     f.tex_w = c->tex_w; f.tex_h = c->tex_h;
     f.vertex_count = c->nv;
+    f.index_count = c->ni;
     f.ntri = c->ni / 3;
     f.geo = (GeomRec*)sl.geo.p;
     f.geo_full = (GeomFull*)sl.geo_full.p;
@@ -548,12 +558,12 @@ DeviceFrame make_frame(swr_context* c, int si, uint64_t frame, const float m[16]
     f.defer_big = 0;
     f.redo_dev = (uint32_t*)c->redo_cnt.p;
     f.host_redo = c->h_pairs_dev + 2 * swr_context::PAIR_RING + 1;
-    f.k32 = (c->k32_ok && f.redo_dev) ? 1 : 0;
+    f.k32 = (c->k32_ok && c->dbg_k32 && f.redo_dev) ? 1 : 0;
     f.tile_count = tb + CNT_WORDS;
     f.tile_start = tb + CNT_WORDS + tiles_of(c->tg);
     f.tile_cursor = tb + CNT_WORDS + 2 * tiles_of(c->tg) + 1;
     f.ranges = (uint2*)sl.ranges.p;
-    f.plan = plan_binning(f.ntri, tiles_of(c->tg));
+    f.plan = plan_binning(f.ntri, tiles_of(c->tg), c->dbg_bin_mode == 3);
 #ifndef SWR_TUNE_IDLE_BIN_G
 #define SWR_TUNE_IDLE_BIN_G 512
 #endif
@@ -568,9 +578,8 @@ DeviceFrame make_frame(swr_context* c, int si, uint64_t frame, const float m[16]
     f.bin_matrix = (uint32_t*)sl.bin_matrix.p;
     f.live = (uint32_t*)sl.live.p;
     // Groups of the stream whose projected box misses this context's band (or the framebuffer) are skipped by
-    // k_setup_hist; the test costs one lane-pass per workgroup, so it is always on (SWR_CULL=0 switches it off).
-    static const int cull_mode = getenv("SWR_CULL") ? atoi(getenv("SWR_CULL")) : 1;
-    f.live_parity = cull_mode != 0 ? 0 : -1;
+    // k_setup_hist; the test costs one lane-pass per workgroup, so it is always on (SWR_DEBUG_CULL = 0 switches it off).
+    f.live_parity = c->dbg_cull != 0 ? 0 : -1;
     f.bins = (uint32_t*)sl.bins.p;
     f.capacity = c->capacity;
     f.fixed_bins = (c->fixed_mode && f.ntri > 0) ? 1 : 0;
@@ -617,7 +626,7 @@ int enqueue_frame(swr_context* c) {
     if (const int f = sticky(c)) return f;      // a failed context posts nothing more
     c->hp_begin();
     {
-        const BinPlan plan = plan_binning(c->ni / 3, tiles_of(c->tg));
+        const BinPlan plan = plan_binning(c->ni / 3, tiles_of(c->tg), c->dbg_bin_mode == 3);
         if (plan.use_lds && !c->fixed_mode) {
             const size_t need = (size_t)plan.G * (size_t)tiles_of(c->tg) * 4;
             bool grow = false;
@@ -709,6 +718,9 @@ int enqueue_frame(swr_context* c) {
         const uint32_t redo = __atomic_load_n(&c->h_pairs[2 * swr_context::PAIR_RING + 1], __ATOMIC_RELAXED);
         if ((uint64_t)redo * 8u * 50u > (uint64_t)tiles_of(c->tg)) { c->k32_ok = false; f.k32 = 0; }
     }
+    // ... and such a frame sorts its bins inside the raster workgroups (the LDS the narrow keys leave free): no k_sort_bins
+    // launch — unless the frame defers triangles that cover hundreds of tiles, which k_sort_bins appends to the bins
+    if (c->dbg_insort && frame_uses_k32(f) && !f.defer_big && !f.skip_sort && sort_stream_mode < 0) { f.insort = 1; f.skip_sort = 1; }
     const bool all = c->timing >= 2;
     if (f.ntri <= 0) { int rc = sync_streams(c); if (rc) return rc; pair_word(c, frame) = 0; }
     if (!f.fixed_bins) fill_word(c, frame) = 0;
@@ -954,9 +966,9 @@ int single_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vert
     if ((rc = ensure(c, c->indices, (size_t)index_count * 8))) return rc;
     if ((rc = ensure(c, c->tri_rgb, (size_t)index_count * 16))) return rc;
     const int64_t ntri = index_count / 3;
-    // SWR_SORT=0: keep index order (the original index still travels in GeomRec.flags);
-    // SWR_SORT=-1: behave as for a scene of 2^24 primitives or more (no reordering, slot == index) — test hook
-    static const int sort_mode = getenv("SWR_SORT") ? atoi(getenv("SWR_SORT")) : 1;
+    // SWR_DEBUG_STREAM_ORDER 0: keep index order (the original index still travels in GeomRec.flags);
+    // -1: behave as for a scene of 2^24 primitives or more (no reordering, slot == index) — test hook
+    const int sort_mode = c->dbg_stream_order;
     const bool reorder = sort_mode == 1 && !oneshot && ntri > 1 && ntri < SORT_MAX_TRIS;
     const size_t sort_bytes = reorder ? stream_sort_temp_bytes(ntri) : 0;
     if ((rc = ensure(c, c->tri_xyz, (size_t)index_count * 16))) return rc;
@@ -990,8 +1002,7 @@ int single_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vert
     // One-shot scenes with an index array worth cutting up (>= 4 MiB): the index check and the stream of chunk k run on
     // the binning stream while chunk k+1 is on the link (a copy from pageable memory returns when its bytes are staged)
     hipStream_t side = c->bin_stream_own && c->bin_stream_own != c->stream ? c->bin_stream_own : nullptr;
-    const char* const min_env = getenv("SWR_ONESHOT_MIN_TRIS");          // test hook: chunk small scenes too
-    const int64_t chunk_min = min_env ? std::max<int64_t>(64, atoll(min_env)) : (int64_t)1 << 18;
+    const int64_t chunk_min = c->dbg_oneshot_min_tris;                   // (SWR_DEBUG_ONESHOT_MIN_TRIS: chunk small scenes too)
     const bool chunked = oneshot && side && sort_mode != -1 && ntri >= chunk_min && ntri < SORT_MAX_TRIS;
     if (chunked) {
         // two chunks, the second one small: every extra copy call from pageable memory costs the link ~30 us, the last
@@ -1039,8 +1050,15 @@ int single_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vert
     c->ni = index_count;
     c->has_scene = true;
     c->h_pairs[swr_context::PAIR_RING] = 0xFFFFFFFFu;       // fullest bin of the new scene: unknown (sort)
-    c->fixed_allowed = true;
-    c->fixed_mode = false;                                  // (re-sized below or at swr_target_set)
+    // What earlier frames taught the context about this (primitive count, tile grid) pair survives the upload — the regions a
+    // crowded tile made the host grow, a scene that needed exact bins, a scene whose depth frames belong on the 64-bit keys: the
+    // reference's calling pattern uploads the SAME mesh on every call (GpuRenderer.swift:41-71), and re-learning it would cost
+    // every such call a second frame.  A different primitive count starts from the first guess again.
+    if (index_count / 3 != c->sized_ntri) {
+        c->fixed_allowed = true;
+        c->fixed_mode = false;                              // (re-sized below or at swr_target_set)
+        c->k32_ok = true;
+    }
     if (!c->has_target) {
         const uint64_t want = (uint64_t)(index_count / 3) * 2 + 65536;
         return ensure_capacity(c, (uint32_t)std::min<uint64_t>(want, 0xFFFFFFF0ull));
@@ -1134,8 +1152,11 @@ int single_target_set(swr_context* c, int64_t width, int64_t height, int64_t row
     c->tg = t;
     c->has_target = true;
     c->h_pairs[swr_context::PAIR_RING] = 0xFFFFFFFFu;       // fullest bin on the new target: unknown (sort)
-    c->fixed_allowed = true;
-    c->fixed_mode = false;
+    if (tiles_of(t) != c->sized_tiles) {                    // (see single_scene_upload)
+        c->fixed_allowed = true;
+        c->fixed_mode = false;
+        c->k32_ok = true;
+    }
     return size_bins(c);
 }
 
@@ -1143,8 +1164,10 @@ int check_draw_args(swr_context* c, uint32_t flags, int32_t primitive_type) {
     if (primitive_type != SWR_PRIMITIVE_TRIANGLE && primitive_type != SWR_PRIMITIVE_LINE &&
         primitive_type != SWR_PRIMITIVE_VERTICES)
         return fail(c, SWR_ERR_UNSUPPORTED, "unknown primitive type %d", primitive_type);
-    if (flags & ~(uint32_t)(SWR_FLAG_DEPTH_TEST | SWR_FLAG_NO_COLOR | SWR_FLAG_METAL_RULES))
+    if (flags & ~(uint32_t)(SWR_FLAG_DEPTH_TEST | SWR_FLAG_NO_COLOR | SWR_FLAG_METAL_RULES | SWR_FLAG_REAL_LINES))
         return fail(c, SWR_ERR_BAD_ARG, "unknown flag bits 0x%x", flags);
+    if ((flags & SWR_FLAG_REAL_LINES) && primitive_type != SWR_PRIMITIVE_LINE)
+        return fail(c, SWR_ERR_BAD_ARG, "SWR_FLAG_REAL_LINES only applies to .line primitives");
     return SWR_OK;
 }
 
@@ -1826,6 +1849,8 @@ int swr_render(swr_context* c, const swr_render_pass* p) {
     // the pass carries its own fragment stage: NULL material = the reference's passthrough
     if ((rc = swr_material_set(c, p->material))) return rc;
     if ((rc = swr_target_set(c, p->width, p->height, 0, p->height))) return rc;
+    const swr_context* kf = c->kids.empty() ? c : c->kids[0];
+    const uint64_t frames0 = kf->frame_no;
     if ((rc = swr_draw_primitives(c, p->transform, p->flags, p->primitive_type))) return rc;
     // colour and depth leave every device together (two copy streams each); synchronous on return like
     // scheduleAndWait (Metal+Extensions.swift:57-67)
@@ -1835,6 +1860,7 @@ int swr_render(swr_context* c, const swr_render_pass* p) {
     if ((rc = swr_present_wait(c))) return rc;
     const auto t3 = clk::now();
     c->rt.draw_ms = ms(t1, t2);
+    c->rt.frames = (int32_t)(kf->frame_no - frames0);            // 1, or 2 when the bins had to grow and the frame was redrawn
     c->rt.gather_ms = ms(t2, t3);
     c->rt.total_ms = ms(t0, t3);
     return SWR_OK;
@@ -1844,6 +1870,47 @@ int swr_render_timings(swr_context* c, swr_render_times* out) {
     if (!c || !out) return SWR_ERR_BAD_ARG;
     *out = c->rt;
     return SWR_OK;
+}
+
+int swr_debug_set(swr_context* c, int key, int64_t value) {
+    if (!c) return SWR_ERR_BAD_ARG;
+    if (is_group(c)) {
+        int rc = SWR_OK;
+        for (swr_context* k : c->kids) { const int r = swr_debug_set(k, key, value); if (r && !rc) { rc = r; c->err = k->err; } }
+        return rc;
+    }
+    switch (key) {
+        case SWR_DEBUG_STREAM_ORDER:
+            if (value < -1 || value > 1) break;
+            c->dbg_stream_order = (int)value; return SWR_OK;
+        case SWR_DEBUG_CULL:
+            if (value < 0 || value > 1) break;
+            c->dbg_cull = (int)value; return SWR_OK;
+        case SWR_DEBUG_BIN_MODE: {
+            if (value < 0 || value > 3) break;
+            c->dbg_bin_mode = (int)value;
+            // the layout of the bins follows the mode: size them again for what is resident (streams idle first)
+            if (c->has_scene && c->has_target) {
+                int rc = swr_sync(c);
+                if (rc) return rc;
+                c->fixed_allowed = true; c->fixed_mode = false;
+                return size_bins(c);
+            }
+            return SWR_OK;
+        }
+        case SWR_DEBUG_ONESHOT_MIN_TRIS:
+            if (value < 0) break;
+            c->dbg_oneshot_min_tris = std::max<int64_t>(64, value); return SWR_OK;
+        case SWR_DEBUG_DEPTH_KEYS32:
+            if (value < 0 || value > 1) break;
+            c->dbg_k32 = value != 0; return SWR_OK;
+        case SWR_DEBUG_RASTER_SORT:
+            if (value < 0 || value > 1) break;
+            c->dbg_insort = value != 0; return SWR_OK;
+        default:
+            return fail(c, SWR_ERR_BAD_ARG, "swr_debug_set: unknown key %d", key);
+    }
+    return fail(c, SWR_ERR_BAD_ARG, "swr_debug_set: value %lld out of range for key %d", (long long)value, key);
 }
 
 int swr_debug_fault(swr_context* c, int fault) {

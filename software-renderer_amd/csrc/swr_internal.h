@@ -60,7 +60,7 @@ struct BinPlan {
     int chunk;          // primitives per workgroup
     size_t lds_bytes;   // tiles * 4
 };
-BinPlan plan_binning(int64_t ntri, int ntiles);
+BinPlan plan_binning(int64_t ntri, int ntiles, bool force_atomic);
 int live_groups_per_workgroup(int64_t ntri, int G);
 
 // Everything one frame needs, all device pointers.  colour/depth are band-local: element
@@ -79,6 +79,7 @@ struct DeviceFrame {
     const float4* texels;          // texture of swr_texture_upload, converted to (r,g,b,a) floats
     int32_t tex_w, tex_h;
     int64_t vertex_count;
+    int64_t index_count;           // (.vertices / .line passes: ntri = index_count / 3 is the triangle count only)
     int64_t ntri;
     GeomRec* geo;
     GeomFull* geo_full;
@@ -87,6 +88,7 @@ struct DeviceFrame {
     uint32_t* counters;            // [CNT_WORDS]
     uint32_t* host_counters;       // device-visible address of the pinned host copy
     uint32_t* host_max;            // pinned host word: entries of the frame's fullest bin (written by k_fill_lds; may be NULL)
+    int32_t insort;                // 1: k_raster_depth sorts every bin itself (no k_sort_bins launch for this frame)
     int32_t k32;                   // 1: depth-only z-tested frames take the 32-bit depth keys (k_raster_depth)
     uint32_t* redo_dev;            // device word: tiles k_raster_depth had to raster again (sampled)
     uint32_t* host_redo;           // pinned host word that receives it one launch later
@@ -141,6 +143,7 @@ void launch_scan(const DeviceFrame& f, hipStream_t s);
 bool launch_fill(const DeviceFrame& f, hipStream_t s, hipEvent_t stop = nullptr);
 bool launch_sort_bins(const DeviceFrame& f, hipStream_t s, hipEvent_t stop = nullptr);
 bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop = nullptr);
+bool frame_uses_k32(const DeviceFrame& f);   // the frame's raster is k_raster_depth (32-bit depth keys, sorts its bins itself)
 void launch_points_or_lines(const DeviceFrame& f, int primitive_type, hipStream_t s);
 
 }  // namespace swr

@@ -276,7 +276,10 @@ __device__ __forceinline__ void decode_vertices(const GeomFull* __restrict__ ful
 // (RANGE_NONE_X when the bbox misses the band).
 // (MT = the Metal rules, a compile-time flag in k_bin: as a run-time select hipcc evaluates round() for every vertex of
 // every frame, 30 of the 385 vector instructions per triangle)
-template <bool MT>
+// (AFF = the transform's last row is (0, 0, 0, 1) — identity, orthographic, any affine map: w is then exactly 1 for every
+// finite vertex (0*x + 0*y + 0*z + 1, :160) and x / 1 = x (:162), so the nine IEEE divisions per triangle are skipped; a
+// non-finite vertex makes sx / sy non-finite either way and the triangle is skipped either way.  Chosen by the host, k_bin only.)
+template <bool MT, bool AFF = false>
 __device__ __forceinline__ uint2 setup_triangle_r(const SetupArgs& a, int64_t p, const float4& xa, const float4& xb, const float4& xc);
 __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p, const float4& xa, const float4& xb, const float4& xc) {
     return a.metal ? setup_triangle_r<true>(a, p, xa, xb, xc) : setup_triangle_r<false>(a, p, xa, xb, xc);
@@ -286,7 +289,7 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
     return setup_triangle(a, p, a.tri_xyz[3 * p + 0], a.tri_xyz[3 * p + 1], a.tri_xyz[3 * p + 2]);
 }
 // ... with the corners already loaded (k_setup_hist fetches those of its next group while it works on this one)
-template <bool MT>
+template <bool MT, bool AFF>
 __device__ __forceinline__ uint2 setup_triangle_r(const SetupArgs& a, int64_t p, const float4& xa, const float4& xb, const float4& xc) {
     uint2 range = make_uint2(RANGE_NONE_X, 0u);
     const uint32_t orig = a.reordered ? __float_as_uint(xa.w) : 0u;
@@ -304,9 +307,9 @@ __device__ __forceinline__ uint2 setup_triangle_r(const SetupArgs& a, int64_t p,
             // Vertex.apply(transform:) (:159-163) through the vertex_shader hook
             VertexOut vo = vertex_shader(make_float3(xs[k].x, xs[k].y, xs[k].z),
                                          make_float3(cs[k].x, cs[k].y, cs[k].z), a.m);
-            const float nx = vo.pos.x / vo.pos.w;
-            const float ny = vo.pos.y / vo.pos.w;
-            const float nz = vo.pos.z / vo.pos.w;
+            const float nx = AFF ? vo.pos.x : vo.pos.x / vo.pos.w;
+            const float ny = AFF ? vo.pos.y : vo.pos.y / vo.pos.w;
+            const float nz = AFF ? vo.pos.z : vo.pos.z / vo.pos.w;
             // convertedToScreen (:165-171)
             const float u = nx * 0.5f + 0.5f;
             const float v = ny * -0.5f + 0.5f;
@@ -767,7 +770,7 @@ __device__ __forceinline__ int tiles_of_box(const PixBox& b) {
     return b.x0 <= b.x1 ? (b.x1 / TILE_W - b.x0 / TILE_W + 1) * (b.y1 / TILE_H - b.y0 / TILE_H + 1) : 0;
 }
 
-template <int BT, bool MT, bool DEFER>
+template <int BT, bool MT, bool DEFER, bool AFF = false>
 // Register budget of the plain kernel: 56 VGPRs (tools/vgprs.sh) — with 58 the pipelined cfg4 frame measured 4 % slower (one of its waves has
 // to fit beside five raster waves of 88); neither launch bounds nor amdgpu_waves_per_eu make this hipcc keep it, the source does.
 __global__ __launch_bounds__(BT) void k_bin(BinArgs b) {
@@ -821,7 +824,7 @@ __global__ __launch_bounds__(BT) void k_bin(BinArgs b) {
             }
             uint2 r = make_uint2(RANGE_NONE_X, 0u);
             if (p < a.ntri) {
-                r = setup_triangle_r<MT>(a, p, xa, xb, xc);
+                r = setup_triangle_r<MT, AFF>(a, p, xa, xb, xc);
                 if (DEFER && tiles_of_box(unpack_box(r)) > BIN_BIG_TILES) {
                     const uint32_t e = atomicAdd(&b.fill[CNT_BIGLIST], 1u);
                     if (e < BIGLIST_CAP) {                           // (a full list: walked like any other)
@@ -1034,8 +1037,12 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_bins(uint32_t* __restrict
             __syncthreads();
             const uint32_t grown = app_count;
             // (no frame-wide counter is touched here — thousands of workgroups on one word would serialise in the L2: k_bin
-            // has counted the deferred pairs, and k_raster bounds the fullest bin by k_bin's maximum + the length of the list)
+            // has counted the deferred pairs — except by a tile that the appended triangles really push over its region: that
+            // rare tile raises the frame's largest fill, which is what k_raster and the host test.  Round 3 bounded the fullest
+            // bin by k_bin's maximum + the length of the list: a frame whose deferred triangles miss its fullest tile was then
+            // declared overflowed, rastered empty and redrawn for nothing)
             if (tid == 0 && grown != count) fill[CNT_WORDS + blockIdx.x] = grown;
+            if (tid == 0 && grown > fixed_cap) atomicMax(&fill[CNT_MAXFILL], grown);
             count = grown;
         }
         b1 = b0 + min(count, fixed_cap);
@@ -1101,6 +1108,8 @@ struct RasterArgs {
     uint32_t* host_pairs;   // fixed-stride bins: pinned host words for the frame's pair total, its largest fill (the overflow
     uint32_t* host_fill;    // test) and the same for the host's sort heuristic — k_bin leaves them in device counters
     uint32_t* host_max;
+    int slot_bits24;    // every stream slot fits 24 bits (it can ride in a record's flag word)
+    int insort;         // 32-bit keys: the bins are unsorted and tagged (no k_sort_bins ran): the workgroup sorts its bin in LDS
     int vs_log;         // 2^vs_log workgroups per tile, each owning TILE_H >> vs_log of its rows (small grids, see launch_raster)
     uint32_t* redo_dev; // k_raster_depth: tiles (one in REDO_SAMPLE) that had to be rastered again with 64-bit keys, since the last launch
     uint32_t* host_redo;    // ... handed to the host's pinned word by the next launch (the host then switches the scene to the 64-bit kernel)
@@ -1111,6 +1120,9 @@ constexpr int REDO_SAMPLE = 8;
 // 64-bit visibility keys (orderable depth << 32 | primitive, or ~primitive without z-test): every frame that needs the
 // winner's identity — colour frames, painter's order, the Metal rules.
 constexpr int RASTER_QCAP = 128;         // ring entries per wave (see raster_tile)
+constexpr int RASTER_SORT_SEG = 1024;    // bin entries a raster workgroup sorts in its own LDS (fuller bins stay unsorted; four per
+                                         // thread: eight cost the kernel 5 VGPRs at its start, over the budget of 88)
+constexpr int RASTER_SORT_WORDS = 2048;  // LDS words behind that: the sorted entries, or the records of sorted positions 256..511
 struct alignas(16) RasterLds64 {
     unsigned long long keys[TILE_W * TILE_H];
     float4 tabAB[2 * RASTER_THREADS];    // per triangle of the batch: (t00, t01, t10, t11) | (za, zb, zc, (C.x - X0) | (C.y - Y0) << 16)
@@ -1121,38 +1133,35 @@ struct alignas(16) RasterLds64 {
 // 32-bit keys: depth-only z-tested frames under the CPU rules (BASELINE config 4).  The image of such a frame is the
 // per-pixel minimum of the fragment depths (Renderer.swift:257-261); WHICH primitive wins a tie cannot be seen in it, except
 // through the sign of a zero (and never through anything else: equal non-zero floats have equal bits).  So the key is the
-// depth itself and the atomic an LDS float / integer minimum — no orderable map, no index word, half the LDS traffic — and
-// a tile whose result holds a value the 32-bit order cannot vouch for (below) is rastered again with the 64-bit keys.
+// depth itself and the atomic an LDS float minimum — no orderable map, no index word, half the LDS traffic — and a tile
+// whose result holds a zero (below) is rastered again with the 64-bit keys.
 struct alignas(16) RasterLds32 {
-    float keys[TILE_W * TILE_H];
+    float keys[TILE_W * TILE_H + 16];    // (+ padding: a 4-pixel visit that starts at the tile's last pixel may address three floats past it)
     float4 tabAB[2 * RASTER_THREADS];
     uint32_t tabP[4];                    // (unused: no index word)
     uint32_t queue[RASTER_THREADS / 64][RASTER_QCAP];
     uint32_t next_chunk;
     uint32_t redo;                       // a thread of the resolve met a key the 64-bit path has to decide
+    // The 8 KB the narrow keys leave free hold the tile's bin, counting-sorted by size class by the workgroup itself
+    // (raster_tile, INSORT): such frames need no k_sort_bins launch in front of the raster.
+    uint32_t cls_cnt[64];
+    uint32_t sorted[RASTER_SORT_WORDS];
 };
-// SWR_K32_INT = 1: ds_min_i32 on the raw float bits.  Exact for depths > +0 (positive floats, denormals included, order like
-// their bits; a positive NaN lies above +inf = the empty key and never wins; +inf never changes anything).  Any negative
-// int — a negative depth, -0, a negative NaN — beats every positive one, and +0 beats every positive depth, so a pixel
-// whose true minimum is not > +0 always ends with a key <= 0 (as int): the resolve sees it and the tile takes the 64-bit
-// path.  = 0: ds_min_f32 (tools/micro/ds_min_f32_semantics.hip records what the LDS does with NaN, -0 and denormals).
-#ifndef SWR_K32_INT
-#define SWR_K32_INT 1
-#endif
+static_assert(sizeof(RasterLds32) <= sizeof(RasterLds64), "the 32-bit path must not need more LDS than the 64-bit one (5 workgroups per CU)");
+// The atomic is ds_min_f32.  What the LDS does with the special values was measured on the device
+// (tools/micro/ds_min_f32_semantics.hip, profiles/r04/ds_min_f32_semantics.txt): IEEE minNum — a quiet NaN operand leaves the
+// memory untouched (a NaN depth never passes '<', :258: exactly that), denormals compare exactly, -inf / +inf order as
+// numbers, and -0 counts as smaller than +0 whatever the order of arrival.  The last point is the one thing the 32-bit key
+// cannot get right — under '<' the two zeros are equal and the FIRST DRAWN keeps its sign — so a tile whose resolve meets a
+// zero of either sign (or a NaN: only a signalling NaN input could put one there) is rastered again with the 64-bit keys.
+// (A raw-bits ds_min_i32 variant was built first: exact for depths > 0 only, and cfg4's spans reach outside their triangles
+// far enough for extrapolated depths below zero to win in most tiles — 700 us per frame in the fallback.)
 __device__ __forceinline__ void k32_min(float* p, float d) {
-#if SWR_K32_INT
-    atomicMin(reinterpret_cast<int*>(p), __float_as_int(d));
-#else
     __hip_atomic_fetch_min(p, d, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#endif
 }
 // does the resolve have to hand this tile to the 64-bit path?
 __device__ __forceinline__ bool k32_undecided(float k) {
-#if SWR_K32_INT
-    return __float_as_int(k) <= 0;
-#else
-    return !(k != 0.0f);                 // +-0 (the sign is the winner's, :257) or NaN
-#endif
+    return !(k != 0.0f);                 // +-0 (the sign is the first-drawn winner's, :257-261) or NaN
 }
 
 constexpr unsigned long long KEY_EMPTY = ~0ull;
@@ -1350,8 +1359,8 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
     // an overflowed frame (more pairs than the bins hold / a tile region too small) is rastered empty: the host grows the
     // bins and redraws it
     uint32_t b0 = 0u, b1 = 0u;
-    // the fullest bin of the frame, bounded: k_bin's maximum + the deferred triangles k_sort_bins may have appended to it
-    const uint32_t max_fill = a.fixed_cap ? a.fill[CNT_MAXFILL] + min(a.fill[CNT_BIGLIST], BIGLIST_CAP) : 0u;
+    // the fullest bin of the frame: k_bin's maximum, raised by k_sort_bins if the deferred triangles it appended overfilled a tile
+    const uint32_t max_fill = a.fixed_cap ? a.fill[CNT_MAXFILL] : 0u;
     if (a.fixed_cap && blockIdx.x == 0 && threadIdx.x == 0) {
         *a.host_pairs = a.fill[CNT_PAIRS];
         *a.host_fill = max_fill;
@@ -1402,7 +1411,61 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
     if (tid == 0) next_chunk = RASTER_THREADS / 64;
     const uint32_t slot0 = chunk * csz + (uint32_t)lane;
     const bool have0 = (uint32_t)lane < csz && slot0 < m;
-    if (have0 && VAR != 9 && VAR != 11) {
+    // 32-bit keys: the workgroup sorts its bin by size class itself (what k_sort_bins does in a launch of its own for the
+    // other kernels), in the LDS the narrow keys leave free: entries -> registers, class counts by returning LDS atomics,
+    // every wave scans the 33 counts for itself (no barrier for the prefix), scatter in class order, heaviest first.  Two
+    // barriers more than the clear needs.  Row-split tiles (every wave walks every chunk) do not care about the order and are
+    // left alone.
+    //  * Bins of up to 512 entries (cfg4: 365 on average): the RECORDS travel too.  Every thread gathers the records of its
+    //    two entries right behind the entries — the two round trips to memory overlap the clear and the first barrier, as the
+    //    prefetch of the first chunk always did — and writes them to their sorted positions: positions 0..255 (the four waves'
+    //    first chunks, read back right after the last barrier, each wave from its own slice) into the per-triangle tables,
+    //    which nothing uses before the first chunk's setup; positions 256..511 into the 8 KB the narrow keys leave free.  The
+    //    chunks then read entry and record from LDS; nothing is gathered after the sort.  (Entries only, records gathered
+    //    after the sort: k_raster_depth 64 -> 68 us — one more round trip exposed per workgroup.)  The stream slot travels in
+    //    bits 8..31 of the record's flag word, where the 64-bit keys keep the original index.
+    //  * Fuller bins, up to 1 024 entries: entries only.
+    constexpr int SORT_PER = RASTER_SORT_SEG / RASTER_THREADS;
+    constexpr int REC_PER = 2;                                  // entries per thread whose records are exchanged
+    constexpr uint32_t REC_MAX = REC_PER * RASTER_THREADS;
+    bool insort = false, inrec = false;
+    uint32_t s_ent[K32 ? SORT_PER : 1];
+    int4 s_r0[K32 ? REC_PER : 1];
+    float4 s_r1[K32 ? REC_PER : 1];
+    // record of sorted position sp: (tabA[sp], tabB[sp]) below 256, the pair 2 (sp - 256) of `sorted` from there on
+    uint32_t* sorted_base = nullptr;
+    if constexpr (K32) sorted_base = L.sorted;
+    auto rec_q0 = [&](uint32_t sp) -> int4* {
+        return sp < (uint32_t)RASTER_THREADS ? reinterpret_cast<int4*>(tabA) + sp : reinterpret_cast<int4*>(sorted_base) + 2 * (sp - RASTER_THREADS);
+    };
+    auto rec_q1 = [&](uint32_t sp) -> float4* {
+        return sp < (uint32_t)RASTER_THREADS ? tabB + sp : reinterpret_cast<float4*>(sorted_base) + 2 * (sp - RASTER_THREADS) + 1;
+    };
+    if constexpr (K32) {
+        static_assert(sizeof(L.sorted) >= (size_t)(REC_MAX - RASTER_THREADS) * 32, "the records of positions 256.. fit the sorted region");
+        insort = a.insort != 0 && a.tag_class != 0 && !rowsplit && m <= (uint32_t)RASTER_SORT_SEG;
+        inrec = insort && m <= REC_MAX && a.slot_bits24 != 0;
+        if (insort) {
+            if (tid < 64) L.cls_cnt[tid] = 0u;
+#pragma unroll
+            for (int k = 0; k < SORT_PER; k++) {
+                const uint32_t i = (uint32_t)(tid + k * RASTER_THREADS);
+                s_ent[k] = i < m ? a.bins[b0 + i] : 0u;
+            }
+            if (inrec) {
+#pragma unroll
+                for (int k = 0; k < REC_PER; k++) {
+                    const uint32_t pr = s_ent[k] & bin_mask;
+                    s_r0[k] = make_int4(0, 0, 0, 0); s_r1[k] = make_float4(0, 0, 0, 0);
+                    if ((uint32_t)(tid + k * RASTER_THREADS) < m) {
+                        s_r0[k] = reinterpret_cast<const int4*>(a.geo + pr)[0];
+                        s_r1[k] = reinterpret_cast<const float4*>(a.geo + pr)[1];
+                    }
+                }
+            }
+        }
+    }
+    if (!insort && have0 && VAR != 9 && VAR != 11) {
         prim_pre = a.bins[b0 + slot0] & bin_mask;
         q0_pre = reinterpret_cast<const int4*>(a.geo + prim_pre)[0];
         q1_pre = reinterpret_cast<const float4*>(a.geo + prim_pre)[1];
@@ -1417,6 +1480,53 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
         for (int i = tid; i < TILE_W * TILE_H; i += RASTER_THREADS) keys[i] = KEY_EMPTY;
     }
     __syncthreads();
+    if constexpr (K32) {
+        if (insort) {                                                   // (workgroup-uniform)
+            uint32_t s_pos[SORT_PER];
+#pragma unroll
+            for (int k = 0; k < SORT_PER; k++) {
+                s_pos[k] = 0u;
+                if ((uint32_t)(tid + k * RASTER_THREADS) < m) s_pos[k] = atomicAdd(&L.cls_cnt[s_ent[k] >> CLASS_SHIFT], 1u);
+            }
+            __syncthreads();
+            // lane l holds class NUM_CLASSES - 1 - l: exclusive prefix in descending class order (heaviest first)
+            const int cl = NUM_CLASSES - 1 - lane;
+            const uint32_t cv = cl >= 0 ? L.cls_cnt[cl] : 0u;
+            const uint32_t cbase = (uint32_t)wave_incl_add((int)cv) - cv;
+            if (inrec) {
+#pragma unroll
+                for (int k = 0; k < REC_PER; k++) {
+                    const uint32_t cls = s_ent[k] >> CLASS_SHIFT;
+                    const uint32_t sp = (uint32_t)__shfl((int)cbase, (int)(NUM_CLASSES - 1 - cls)) + s_pos[k];
+                    if ((uint32_t)(tid + k * RASTER_THREADS) < m) {
+                        const uint32_t pr = s_ent[k] & bin_mask;
+                        s_r1[k].w = __uint_as_float((__float_as_uint(s_r1[k].w) & ((1u << GEOM_ORIG_SHIFT) - 1u)) | (pr << GEOM_ORIG_SHIFT));
+                        *rec_q0(sp) = s_r0[k];
+                        *rec_q1(sp) = s_r1[k];
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < SORT_PER; k++) {
+                    const uint32_t cls = s_ent[k] >> CLASS_SHIFT;
+                    const uint32_t base = (uint32_t)__shfl((int)cbase, (int)(NUM_CLASSES - 1 - cls));
+                    if ((uint32_t)(tid + k * RASTER_THREADS) < m) L.sorted[base + s_pos[k]] = s_ent[k] & bin_mask;
+                }
+            }
+            __syncthreads();
+            if (have0) {
+                if (inrec) {
+                    q0_pre = *rec_q0(slot0);
+                    q1_pre = *rec_q1(slot0);
+                    prim_pre = __float_as_uint(q1_pre.w) >> GEOM_ORIG_SHIFT;
+                } else {
+                    prim_pre = L.sorted[slot0];
+                    q0_pre = reinterpret_cast<const int4*>(a.geo + prim_pre)[0];
+                    q1_pre = reinterpret_cast<const float4*>(a.geo + prim_pre)[1];
+                }
+            }
+        }
+    }
 
     while (VAR != 9 && VAR != 11 && chunk < nchunks) {
         const uint32_t e = chunk * csz + (uint32_t)lane;
@@ -1600,7 +1710,12 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
             }
             const uint32_t e2 = chunk_next * csz + (uint32_t)lane;
             have_next = chunk_next < nchunks && (uint32_t)lane < csz && e2 < m;
-            if (have_next) prim_pre = a.bins[b0 + e2] & bin_mask;
+            if constexpr (K32) {
+                if (have_next && inrec) prim_pre = e2;      // (the sorted position: entry and record are read from LDS below)
+                else if (have_next) prim_pre = insort ? L.sorted[e2] : a.bins[b0 + e2] & bin_mask;
+            } else {
+                if (have_next) prim_pre = a.bins[b0 + e2] & bin_mask;
+            }
         };
         auto dense = [&](auto SLc) {
             constexpr int SL = decltype(SLc)::value;            // log2 of the 4-pixel groups per visit
@@ -1724,24 +1839,44 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                             if constexpr (!K32) { if (live) atomicMin(&keys[lidx0 + qq], key); }
                         }
                     } else if (K32) {
-                        // 32-bit keys: the depth is the key.  No -0 -> +0, no NaN / +inf clamp, no orderable map: a result the
-                        // plain order of the bits cannot vouch for sends the tile to the 64-bit path (k32_undecided, resolve)
+                        // 32-bit keys: the depth is the key (ds_min_f32).  No -0 -> +0, no NaN / +inf clamp, no orderable map: a
+                        // zero in the result sends the tile to the 64-bit path (k32_undecided, resolve)
                         float dx0 = (float)dxi;                              // (x + .5) - cf.x, exact: small integers
                         asm volatile("" : "+v"(dx0));
                         const float dy = (float)dyi;                         // (y + .5) - cf.y
                         const float r0 = ta.y * dy, r1 = ta.w * dy;          // t01*dy, t11*dy
+#ifndef SWR_K32_NANMASK
+#define SWR_K32_NANMASK 0
+#endif
+#if SWR_K32_NANMASK
+                        // Pixels past the end of the span get a NaN offset: their depth is NaN, and the LDS float minimum ignores a
+                        // quiet NaN operand (measured: profiles/r04/ds_min_f32_semantics.txt) — no compare, no EXEC mask and no
+                        // branch per pixel, one mask per visit.  (The four addresses of a live lane stay inside the padded key tile.)
+                        if (nvalid > 0) {
+                            float off[UNIT];
+#pragma unroll
+                            for (int qq = 1; qq < UNIT; qq++) off[qq] = qq < nvalid ? (float)qq : __builtin_nanf("");
+#pragma unroll
+                            for (int qq = 0; qq < UNIT; qq++) {
+                                const float dx = qq == 0 ? dx0 : dx0 + off[qq];
+                                const float w0 = ta.x * dx + r0;
+                                const float w1 = ta.z * dx + r1;
+                                const float w2 = 1.0f - w0 - w1;
+                                const float d = tb.x * w0 + tb.y * w1 + tb.z * w2;     // :257
+                                if constexpr (K32) k32_min(&keys[lidx0 + qq], d);
+                            }
+                        }
+#else
 #pragma unroll
                         for (int qq = 0; qq < UNIT; qq++) {
                             const float dx = qq == 0 ? dx0 : dx0 + (float)qq;
                             const float w0 = ta.x * dx + r0;
                             const float w1 = ta.z * dx + r1;
                             const float w2 = 1.0f - w0 - w1;
-                            float d = tb.x * w0 + tb.y * w1 + tb.z * w2;     // :257
-#if !SWR_K32_INT
-                            d = fminf(d, INFINITY);                          // NaN -> +inf (see tools/micro/ds_min_f32_semantics.hip)
-#endif
+                            const float d = tb.x * w0 + tb.y * w1 + tb.z * w2;     // :257
                             if constexpr (K32) { if (qq < nvalid) k32_min(&keys[lidx0 + qq], d); }
                         }
+#endif
                     } else if (ZTEST) {
                         float dx0 = (float)dxi;                              // (x + .5) - cf.x, exact: small integers
                         asm volatile("" : "+v"(dx0));                        // keep dx0 + q a float add (2 cycles), not add + convert (6)
@@ -1844,7 +1979,13 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
         }
         // the next chunk (wave-uniform, chosen by steal_next): its records, now that the bin entries have arrived
         chunk = chunk_next;
-        if (have_next) {
+        if (K32 && inrec) {
+            if (have_next) {    // (a stolen chunk: positions 256.. only — the first four chunks are the waves' own)
+                q0_pre = reinterpret_cast<const int4*>(sorted_base)[2 * (prim_pre - RASTER_THREADS)];
+                q1_pre = reinterpret_cast<const float4*>(sorted_base)[2 * (prim_pre - RASTER_THREADS) + 1];
+                prim_pre = __float_as_uint(q1_pre.w) >> GEOM_ORIG_SHIFT;
+            }
+        } else if (have_next) {
             q0_pre = reinterpret_cast<const int4*>(a.geo + prim_pre)[0];
             q1_pre = reinterpret_cast<const float4*>(a.geo + prim_pre)[1];
         }
@@ -1856,7 +1997,7 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
     const int W = a.tg.width;
     const bool vec_ok = (W & 3) == 0;
     // 32-bit keys: the key is the depth (an untouched pixel still holds the +inf of the clear, :206); one 16-B LDS read and one
-    // 16-B store per four pixels.  A key that is not > +0 (k32_undecided) is one the 64-bit path has to decide.
+    // 16-B store per four pixels.  A zero of either sign (k32_undecided) is what the 64-bit path has to decide.
     if constexpr (K32) {
         bool undecided = false;
         for (int i = tid; i < TILE_W * TILE_H / 4; i += RASTER_THREADS) {
@@ -2105,7 +2246,7 @@ void k_raster_ext(RasterArgs a) {
     raster_tile<ZTEST, 0, METAL, true, true>(a, L);
 }
 // Depth-only z-tested frames under the CPU rules: 32-bit keys first; the rare tile whose result they cannot vouch for (a
-// depth that is not > +0) is rastered again, by the same workgroup, with the 64-bit keys.  One LDS block for both.
+// zero, whose sign is the first-drawn winner's) is rastered again, by the same workgroup, with the 64-bit keys.  One LDS block for both.
 __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) __attribute__((amdgpu_num_vgpr(SWR_RASTER_VGPRS)))
 void k_raster_depth(RasterArgs a) {
     constexpr size_t BYTES = sizeof(RasterLds64) > sizeof(RasterLds32) ? sizeof(RasterLds64) : sizeof(RasterLds32);
@@ -2148,6 +2289,42 @@ __global__ void k_points(const swr_vertex* __restrict__ vtx, const int64_t* __re
     atomicMax(&order[(size_t)(py - tg.row_begin) * (size_t)tg.width + (size_t)px], (uint32_t)(i + 1));
 }
 
+// PrimitiveType .line under SWR_FLAG_REAL_LINES (opt-in; the default is the reference's empty stub): the reference's own
+// line DDA, draw(line:with:in:) (Renderer.swift:405-419), between the two transformed endpoints of every 2-index primitive,
+// truncated like draw(vertices:) does (:298-299).  x and y are ACCUMULATED floats (x += xStep, :416-417), so the pixels of a
+// line come out of a sequential loop: one lane per line.  Later lines overwrite earlier ones: atomicMax of (index of the
+// line's first vertex reference + 1), resolved by k_points_resolve like .vertices — the colour is the first vertex's.
+constexpr int LINE_MAX_STEPS = 1 << 20;     // longer lines are skipped (include/swr.h, SWR_FLAG_REAL_LINES)
+__global__ void k_lines(const swr_vertex* __restrict__ vtx, const int64_t* __restrict__ idx, int64_t nlines,
+                        float4x4 m, Target tg, uint32_t* __restrict__ order) {
+    const int64_t l = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (l >= nlines) return;
+    int ex[2], ey[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const float4 p = reinterpret_cast<const float4*>(vtx)[2 * idx[2 * l + k]];
+        const VertexOut vo = vertex_shader(make_float3(p.x, p.y, p.z), make_float3(0, 0, 0), m);   // :160
+        const float nx = vo.pos.x / vo.pos.w, ny = vo.pos.y / vo.pos.w;                             // :161
+        const float sx = (nx * 0.5f + 0.5f) * (float)tg.width;                                      // :166-168
+        const float sy = (ny * -0.5f + 0.5f) * (float)tg.height;
+        if (!(fabsf(sx) < COORD_LIMIT) || !(fabsf(sy) < COORD_LIMIT)) return;   // Swift Int(NaN) would trap
+        ex[k] = (int)sx; ey[k] = (int)sy;                                        // :298-299 truncation
+    }
+    const int dx = ex[1] - ex[0], dy = ey[1] - ey[0];                            // :406-407 (|coordinates| < 2^30: no overflow)
+    const int steps = max(abs(dx), abs(dy));                                     // :408
+    if (steps > LINE_MAX_STEPS) return;
+    const float xs = (float)dx / (float)steps, ys = (float)dy / (float)steps;    // :409-410
+    float x = (float)ex[0], y = (float)ey[0];                                    // :412-413
+    const uint32_t tag = (uint32_t)(2 * l + 1);
+    for (int k = 0; k < steps; k++) {                                            // :414
+        const int px = (int)roundf(x), py = (int)roundf(y);                      // :415 rounded(): half away from zero
+        if (px >= 0 && px < tg.width && py >= tg.row_begin && py < tg.row_end)   // the setter drops OOB (:30-36)
+            atomicMax(&order[(size_t)(py - tg.row_begin) * (size_t)tg.width + (size_t)px], tag);
+        x += xs;                                                                 // :416-417
+        y += ys;
+    }
+}
+
 __global__ void k_points_resolve(const swr_vertex* __restrict__ vtx, const int64_t* __restrict__ idx,
                                  uint32_t* __restrict__ color, uint32_t* __restrict__ depth_bits, int64_t n) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
@@ -2179,17 +2356,23 @@ void launch_points_or_lines(const DeviceFrame& f, int primitive_type, hipStream_
     if (n <= 0) return;
     const bool want_color = !(f.flags & SWR_FLAG_NO_COLOR);
     const unsigned blocks = (unsigned)std::min<int64_t>((n + 255) / 256, 4096);
-    const bool points = primitive_type == SWR_PRIMITIVE_VERTICES && want_color && f.ntri > 0;
-    // .line and colour-less passes only clear; .vertices first zeroes the order scratch (= depth bits)
+    const bool points = primitive_type == SWR_PRIMITIVE_VERTICES && want_color && f.index_count >= 3;
+    const bool lines = primitive_type == SWR_PRIMITIVE_LINE && (f.flags & SWR_FLAG_REAL_LINES) && want_color && f.index_count >= 2;
+    // .line (as written: an empty stub) and colour-less passes only clear; .vertices and real lines first zero the order
+    // scratch (= depth bits)
     hipLaunchKernelGGL(k_clear_band, dim3(blocks), dim3(256), 0, s, want_color ? (uint32_t*)f.color : nullptr,
-                       (uint32_t*)f.depth, n, points ? 0u : 0x7F800000u);
-    if (!points) return;
-    const int64_t ni = f.ntri * 3;
+                       (uint32_t*)f.depth, n, (points || lines) ? 0u : 0x7F800000u);
+    if (!points && !lines) return;
+    const int64_t ni = f.index_count;
     float4x4 m;
     for (int c = 0; c < 4; c++)
         m.columns[c] = make_float4(f.m[4 * c + 0], f.m[4 * c + 1], f.m[4 * c + 2], f.m[4 * c + 3]);
-    hipLaunchKernelGGL(k_points, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, s, f.vertices, f.indices, ni, m, f.tg,
-                       (uint32_t*)f.depth);
+    if (lines)
+        hipLaunchKernelGGL(k_lines, dim3((unsigned)((ni / 2 + 63) / 64)), dim3(64), 0, s, f.vertices, f.indices, ni / 2, m, f.tg,
+                           (uint32_t*)f.depth);
+    else
+        hipLaunchKernelGGL(k_points, dim3((unsigned)((ni + 255) / 256)), dim3(256), 0, s, f.vertices, f.indices, ni, m, f.tg,
+                           (uint32_t*)f.depth);
     hipLaunchKernelGGL(k_points_resolve, dim3(blocks), dim3(256), 0, s, f.vertices, f.indices, (uint32_t*)f.color,
                        (uint32_t*)f.depth, n);
 }
@@ -2222,11 +2405,10 @@ int live_groups_per_workgroup(int64_t ntri, int G) {
 }
 
 // LDS binning geometry: G workgroups of BIN_THREADS threads, each owning `chunk` consecutive primitives.
-BinPlan plan_binning(int64_t ntri, int ntiles) {
+BinPlan plan_binning(int64_t ntri, int ntiles, bool force_atomic) {
     BinPlan p{};
     p.lds_bytes = (size_t)ntiles * 4;
-    const char* force = getenv("SWR_BIN_MODE");
-    p.use_lds = p.lds_bytes <= 136 * 1024 && !(force && force[0] == 'a');   // 'atomic' forces the fallback (LDS also holds a workgroup's group list)
+    p.use_lds = p.lds_bytes <= 136 * 1024 && !force_atomic;   // (SWR_DEBUG_BIN_MODE = 3 forces the fallback; the LDS also holds a workgroup's group list)
     p.threads = 256;
     int64_t g = (ntri + p.threads - 1) / p.threads;
     if (g > SWR_TUNE_BIN_G) g = SWR_TUNE_BIN_G;   // 1 per CU (measured best)
@@ -2251,10 +2433,11 @@ hipError_t prepare_device() {
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_bin<256, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_bin<256, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_bin<256, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    if ((e = hipFuncSetAttribute((const void*)k_bin<256, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+#define SWR_BIN_ATTR(MT, DF, AF) \
+    if ((e = hipFuncSetAttribute((const void*)k_bin<256, MT, DF, AF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    SWR_BIN_ATTR(false, false, false) SWR_BIN_ATTR(true, false, false) SWR_BIN_ATTR(false, true, false) SWR_BIN_ATTR(true, true, false)
+    SWR_BIN_ATTR(false, false, true) SWR_BIN_ATTR(true, false, true) SWR_BIN_ATTR(false, true, true) SWR_BIN_ATTR(true, true, true)
+#undef SWR_BIN_ATTR
     return hipFuncSetAttribute((const void*)k_fill_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
@@ -2295,7 +2478,7 @@ void launch_setup_bin(const DeviceFrame& f, hipStream_t s) {
 // region size + the primitives one workgroup owns < 65536.
 uint32_t fixed_cap_max(int64_t ntri, int ntiles) {
     if (ntri <= 0 || ntiles <= 0 || ntri >= (1ll << CLASS_SHIFT)) return 0u;
-    const BinPlan p = plan_binning(ntri, ntiles);
+    const BinPlan p = plan_binning(ntri, ntiles, false);
     if (!p.use_lds || p.threads != 256) return 0u;
     const int64_t own = (int64_t)live_groups_per_workgroup(ntri, p.G) * 64;
     if (own >= 65535 - 1024) return 0u;
@@ -2316,13 +2499,17 @@ bool launch_bin(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     // whose predecessor reported triangles for the list, and whose k_sort_bins runs
     b.biglist = f.biglist; b.defer_ok = (f.biglist && f.defer_big && !f.skip_sort) ? 1 : 0;
     const size_t lds = (size_t)((b.ntiles + 1) / 2) * 4 + (size_t)(b.per + 1) * 4 + 2 * (256 / 64) * 4 + 4;
-    if (b.defer_ok) {
-        if (b.a.metal) SWR_LAUNCH(stop, (k_bin<256, true, true>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b);
-        else SWR_LAUNCH(stop, (k_bin<256, false, true>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b);
+    // the transform's last row is (0, 0, 0, 1): w == 1 for every finite vertex, no perspective divide (setup_triangle_r<.., AFF>)
+    const bool aff = f.m[3] == 0.0f && f.m[7] == 0.0f && f.m[11] == 0.0f && f.m[15] == 1.0f;
+#define SWR_BIN_GO(MT, DF, AF) SWR_LAUNCH(stop, (k_bin<256, MT, DF, AF>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b)
+    if (aff) {
+        if (b.defer_ok) { if (b.a.metal) SWR_BIN_GO(true, true, true); else SWR_BIN_GO(false, true, true); }
+        else { if (b.a.metal) SWR_BIN_GO(true, false, true); else SWR_BIN_GO(false, false, true); }
     } else {
-        if (b.a.metal) SWR_LAUNCH(stop, (k_bin<256, true, false>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b);
-        else SWR_LAUNCH(stop, (k_bin<256, false, false>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b);
+        if (b.defer_ok) { if (b.a.metal) SWR_BIN_GO(true, true, false); else SWR_BIN_GO(false, true, false); }
+        else { if (b.a.metal) SWR_BIN_GO(true, false, false); else SWR_BIN_GO(false, false, false); }
     }
+#undef SWR_BIN_GO
     return stop != nullptr;
 }
 
@@ -2361,10 +2548,10 @@ bool launch_sort_bins(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     return stop != nullptr;
 }
 
-// (A/B and test hook: SWR_K32=0 keeps depth-only frames on the 64-bit keys)
-static bool raster_k32() {
-    static const bool on = !(getenv("SWR_K32") && getenv("SWR_K32")[0] == '0');
-    return on;
+// Does this frame take k_raster_depth (32-bit depth keys)?  Depth-only, z-tested, CPU rules, and the scene has not been moved
+// to the 64-bit kernel by the host (DeviceFrame::k32).
+bool frame_uses_k32(const DeviceFrame& f) {
+    return f.k32 && (f.flags & SWR_FLAG_DEPTH_TEST) && (f.flags & SWR_FLAG_NO_COLOR) && !(f.flags & SWR_FLAG_METAL_RULES);
 }
 
 bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
@@ -2386,6 +2573,8 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     a.fixed_cap = f.fixed_bins ? f.cap_tile : 0u;
     a.host_pairs = f.host_counters; a.host_fill = f.host_fill; a.host_max = f.host_max;
     a.redo_dev = f.redo_dev; a.host_redo = f.host_redo;
+    a.insort = f.insort;
+    a.slot_bits24 = f.ntri < SORT_MAX_TRIS ? 1 : 0;
     const unsigned ntiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
     if (ntiles == 0) return false;
     // Small grids (a small window: the reference app's 512x512 is 128 tiles): four workgroups fit where one tile's
@@ -2430,7 +2619,7 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
         const bool sparse = f.ntri < (int64_t)64 * ntiles;
         if (a.color && sparse) SWR_LAUNCH(stop, (k_raster<true, 0, false, true, 2>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else if (a.color) SWR_LAUNCH(stop, (k_raster<true, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-        else if (f.k32 && raster_k32()) SWR_LAUNCH(stop, k_raster_depth, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        else if (frame_uses_k32(f)) SWR_LAUNCH(stop, k_raster_depth, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else SWR_LAUNCH(stop, (k_raster<true, 0, false, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
     } else {
         if (a.color && f.ntri < (int64_t)64 * ntiles) SWR_LAUNCH(stop, (k_raster<false, 0, false, true, 2>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);

@@ -206,7 +206,14 @@ public:
     // counts differ.  false (the default) uploads on every call, whatever the arrays hold.
     bool staticScene = false;
     uint64_t sceneVersion = 1;          // bump after editing the arrays of a static scene in place
-    void render(const RenderPass& renderPass) { ctx_.render(renderPass, 0, staticScene ? sceneVersion : 0); }
+    // .line passes: false (default) = the reference as written — draw(line:colorBuffer:depthBuffer:) is an empty stub
+    // (Renderer.swift:289-293), the pass only clears; true = draw every line with the reference's own DDA
+    // (draw(line:with:in:), Renderer.swift:405-419; SWR_FLAG_REAL_LINES)
+    bool realLines = false;
+    void render(const RenderPass& renderPass) {
+        const bool lines = realLines && renderPass.primitiveType == PrimitiveType::line;
+        ctx_.render(renderPass, lines ? (uint32_t)SWR_FLAG_REAL_LINES : 0u, staticScene ? sceneVersion : 0);
+    }
 private:
     detail::Context ctx_;
 };
@@ -227,9 +234,11 @@ public:
     // see Renderer::staticScene: the resident mesh of GpuRenderer.swift:32-33,41-67
     bool staticScene = false;
     uint64_t sceneVersion = 1;
+    bool realLines = false;             // see Renderer::realLines
     void render(const RenderPass& renderPass) {
-        ctx_.render(renderPass, metalRules ? (uint32_t)SWR_FLAG_METAL_RULES
-                                           : (depthTest ? (uint32_t)SWR_FLAG_DEPTH_TEST : 0u),
+        const bool lines = realLines && renderPass.primitiveType == PrimitiveType::line;
+        ctx_.render(renderPass, (metalRules ? (uint32_t)SWR_FLAG_METAL_RULES : (depthTest ? (uint32_t)SWR_FLAG_DEPTH_TEST : 0u)) |
+                                    (lines ? (uint32_t)SWR_FLAG_REAL_LINES : 0u),
                     staticScene ? sceneVersion : 0);
     }
 private:

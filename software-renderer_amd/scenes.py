@@ -29,6 +29,7 @@ _M2 = np.uint64(0x94D049BB133111EB)
 FLAG_DEPTH_TEST = 1
 FLAG_NO_COLOR = 2
 FLAG_METAL_RULES = 4
+FLAG_REAL_LINES = 8      # .line primitives: the reference's DDA (Renderer.swift:405-419) instead of its empty stub (:289-293)
 
 
 def splitmix64(seed: int, n: int, offset: int = 0) -> np.ndarray:

@@ -12,7 +12,7 @@ std::atomic<uint32_t> g_fake_fill{7};        // largest tile fill the fake k_bin
 std::atomic<uint32_t> g_fake_pairs{1000};
 
 int live_groups_per_workgroup(int64_t ntri, int G) { return (int)(((ntri + 63) / 64 + G - 1) / (G > 0 ? G : 1)); }
-BinPlan plan_binning(int64_t ntri, int ntiles) {
+BinPlan plan_binning(int64_t ntri, int ntiles, bool) {
     BinPlan p{};
     p.use_lds = true; p.threads = 256; p.G = (int)std::max<int64_t>(1, std::min<int64_t>(256, (ntri + 255) / 256));
     p.chunk = (int)((ntri + p.G - 1) / p.G); p.lds_bytes = (size_t)ntiles * 4;
@@ -51,6 +51,9 @@ bool launch_sort_bins(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     if (f.skip_sort) return false;
     fake_enqueue(s, nullptr, stop);
     return stop != nullptr;
+}
+bool frame_uses_k32(const DeviceFrame& f) {
+    return f.k32 && (f.flags & SWR_FLAG_DEPTH_TEST) && (f.flags & SWR_FLAG_NO_COLOR) && !(f.flags & SWR_FLAG_METAL_RULES);
 }
 bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     const DeviceFrame ff = f;

@@ -177,17 +177,17 @@ def test_scene_identity_skips_the_upload_and_zero_always_uploads(swr, oracle):
 
 
 @pytest.mark.parametrize("bands", [1, 3])
-def test_one_shot_scenes_are_built_behind_the_index_copy(swr, oracle, monkeypatch, bands):
+def test_one_shot_scenes_are_built_behind_the_index_copy(swr, oracle, bands):
     """swr_render without a scene identity (the reference's calling pattern: GpuRenderer copies the arrays every call,
     GpuRenderer.swift:41-67) uploads for ONE frame: index order, the triangle stream built chunk by chunk behind the copy of
-    the index array.  SWR_ONESHOT_MIN_TRIS lowers the size from which the array is cut up (default 2^18 primitives)."""
+    the index array.  swr_debug_set(SWR_DEBUG_ONESHOT_MIN_TRIS) lowers the size from which the array is cut up (default 2^18 primitives)."""
     S = swr.scenes
-    monkeypatch.setenv("SWR_ONESHOT_MIN_TRIS", "64")
     # an indexed mesh (shared vertices), primitive count not a multiple of the 64-slot groups or of the chunk size
     torus = S.cfg2_teapot_scale()
     keep = torus.indices[: 3 * 6001]
     soup = S.random_soup(4999, 640, 360, 0xC0DE, r_ndc=0.06, flags=1, margin=1.05)
     with swr.Context(0, device_count=bands if bands > 1 else 0) as ctx:
+        ctx.debug_set(swr.binding.DEBUG_ONESHOT_MIN_TRIS, 64)
         for v, i, m, w, h, fl in ((torus.vertices, keep, torus.transform, torus.width, torus.height, 1),
                                   (soup.vertices, soup.indices, soup.transform, 640, 360, 1),
                                   (soup.vertices, soup.indices, soup.transform, 640, 360, 0),

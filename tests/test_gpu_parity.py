@@ -329,22 +329,22 @@ def test_cfg5_8k(gpu_ctx, oracle, swr):
     check(gpu_ctx, oracle, s)
 
 
-def test_global_atomic_binning_fallback(swr, oracle, monkeypatch):
-    """The binning path used when the tile table does not fit LDS (forced via SWR_BIN_MODE)."""
-    monkeypatch.setenv("SWR_BIN_MODE", "atomic")
-    for flags in (0, DT):
+def test_global_atomic_binning_fallback(swr, oracle):
+    """The binning path used when the tile table does not fit LDS (forced via swr_debug_set(SWR_DEBUG_BIN_MODE, 3))."""
+    for flags in (0, DT, DT | NC):
         s = swr.scenes.random_soup(5000, 900, 500, 123, r_ndc=0.05, flags=flags, margin=1.1)
         with swr.Context() as ctx:
+            ctx.debug_set(swr.binding.DEBUG_BIN_MODE, swr.binding.BIN_MODE_ATOMIC)
             check(ctx, oracle, s)
 
 
-def test_exact_size_bins_path(swr, oracle, monkeypatch):
+def test_exact_size_bins_path(swr, oracle):
     """The four-kernel binning with exact-size bins (k_setup_hist / k_colscan / k_fill_lds / k_sort_bins): the fallback
-    of the single-launch k_bin (fixed-stride bins), forced via SWR_BIN_MODE."""
-    monkeypatch.setenv("SWR_BIN_MODE", "exact")
-    for flags in (0, DT, 4):
+    of the single-launch k_bin (fixed-stride bins), forced via swr_debug_set(SWR_DEBUG_BIN_MODE, 1)."""
+    for flags in (0, DT, DT | NC, 4):
         s = swr.scenes.random_soup(30000, 1280, 720, 321, r_ndc=0.03, flags=flags & 3, margin=1.1)
         with swr.Context() as ctx:
+            ctx.debug_set(swr.binding.DEBUG_BIN_MODE, swr.binding.BIN_MODE_EXACT)
             if flags == 4:                      # SWR_FLAG_METAL_RULES
                 check_metal(ctx, oracle, s)
             else:
@@ -381,6 +381,57 @@ def test_fixed_stride_bins_regrow_and_fall_back(swr, oracle):
                 ctx.draw(s.transform, s.flags)
             ctx.sync()
             assert_same(ctx.read_color(), ctx.read_depth(), rc, rd, f"crowded tile, resident, {ntri}")
+
+
+@pytest.mark.parametrize("ntri", [20000, 140000])
+def test_one_shot_renders_keep_what_the_first_call_learned(swr, oracle, ntri):
+    """ADVICE r03: swr_render without a scene identity uploads on every call (the reference's pattern, GpuRenderer.swift:41-71);
+    the bin regions a crowded tile made the host grow (20 000 triangles in two tiles) or the switch to exact-size bins
+    (140 000) must survive the next upload of a scene of the same size: the first call draws two frames (overflow, redraw),
+    every later call one."""
+    s = crowded_tile_scene(swr, ntri)
+    rc, rd, _, code = oracle.render_scene(s, oracle.TINV_PER_TRIANGLE)
+    assert code == 0
+    with swr.Context() as ctx:
+        frames = []
+        for _ in range(3):
+            c, d = ctx.render(s.vertices, s.indices, s.transform, s.width, s.height, s.flags)
+            assert_same(c, d, rc, rd, f"crowded tile, {ntri} triangles")
+            frames.append(ctx.render_timings()["frames"])
+        assert frames[0] >= 2 and frames[1:] == [1, 1], frames
+        # a scene of another size starts from the first guess again (and is still right)
+        s2 = swr.scenes.random_soup(3000, s.width, s.height, 9, r_ndc=0.05, flags=s.flags)
+        check(ctx, oracle, s2)
+        assert ctx.render_timings()["frames"] == 1
+
+
+def test_deferred_triangles_do_not_fake_an_overflow(swr, oracle):
+    """600 triangles that each cover the left half of a 1080p frame (deferred list: k_sort_bins appends them per
+    tile) and one tile on the right that holds ~900 small ones, against regions of 1 024 entries: no tile needs more than
+    900 — round 3's bound (fullest bin + length of the list = 1 500) declared the frame overflowed and redrew it."""
+    S = swr.scenes
+    small = crowded_tile_scene(swr, 900)
+    sv = small.vertices.copy()
+    sv[:, 0] = 0.55 + (sv[:, 0] - 0.30) * 0.5            # the crowded tile moves to the right half
+    nb = 600
+    z = S.uniform01(11, nb)
+    big = np.zeros((3 * nb, 3), np.float32)
+    big[0::3] = np.stack([np.full(nb, -0.98), np.full(nb, 0.95), z], 1)
+    big[1::3] = np.stack([np.full(nb, -0.05), np.full(nb, -0.9), z], 1)
+    big[2::3] = np.stack([np.full(nb, -0.98), np.full(nb, -0.95), z], 1)
+    bv = S.pack_vertices(big, S.uniform01(12, 9 * nb).reshape(-1, 3))
+    v = np.ascontiguousarray(np.concatenate([sv, bv]))
+    idx = np.arange(v.shape[0], dtype=np.int64)
+    W, H = small.width, small.height
+    rc, rd, _, code = oracle.render(v, idx, small.transform, W, H, DT | oracle.TINV_PER_TRIANGLE)
+    assert code == 0
+    with swr.Context() as ctx:
+        frames = []
+        for _ in range(3):      # the second call is the first whose k_bin defers (the first one only reports the big triangles)
+            c, d = ctx.render(v, idx, small.transform, W, H, DT, scene_id=77)
+            assert_same(c, d, rc, rd, "deferred triangles + a crowded tile")
+            frames.append(ctx.render_timings()["frames"])
+        assert frames == [1, 1, 1], frames
 
 
 def test_host_mirror_cpp_program(swr):
@@ -442,6 +493,67 @@ def test_points_in_bands(swr, oracle):
             ctx.read_color(color)
             ctx.read_depth(depth)
     assert_same(color, depth, ref_c, ref_d, "points bands")
+
+
+RL = 8      # SWR_FLAG_REAL_LINES
+
+
+@pytest.mark.parametrize("w,h,n,r,seed", [(96, 64, 200, 0.3, 5), (640, 360, 3000, 0.2, 6), (1920, 1080, 20000, 0.05, 7), (33, 17, 64, 0.9, 8)])
+def test_real_lines_opt_in(gpu_ctx, oracle, swr, w, h, n, r, seed):
+    """SWR_FLAG_REAL_LINES (opt-in; SURVEY 8(f) rank 3 'a real .line'): every 2-index primitive drawn with the reference's
+    own DDA (Renderer.swift:405-419), first vertex's colour, later lines overwrite earlier ones; identity and the app's
+    perspective transform; the default .line pass stays the reference's empty stub."""
+    s = swr.scenes.random_soup(n, w, h, seed, r_ndc=r, margin=1.3)
+    idx = s.indices[: 2 * (s.indices.size // 2)]
+    for m in (s.transform, swr.scenes.app_transform(0.4, scale=1.3)):
+        rc_c, rc_d, st, rc = oracle.render(s.vertices, idx, m, w, h, RL, primitive_type=1)
+        assert rc == 0 and st.fragments > 0
+        c, d = gpu_ctx.render(s.vertices, idx, m, w, h, RL, primitive_type=1)
+        assert_same(c, d, rc_c, rc_d, f"real lines {w}x{h}")
+    c, d = gpu_ctx.render(s.vertices, idx, s.transform, w, h, 0, primitive_type=1)
+    assert (c == 0).all() and np.isposinf(d).all()
+
+
+def test_real_lines_overwrite_order_long_lines_bands_and_errors(swr, oracle):
+    S = swr.scenes
+    # many lines through one point: the highest primitive index wins every shared pixel; a few lines far longer than the
+    # screen (steps ~ 10^5: walked, clipped per pixel); one non-finite endpoint (skipped); one beyond 2^20 steps (skipped)
+    n = 400
+    ang = np.linspace(0, np.pi, n, endpoint=False)
+    xyz = np.zeros((2 * n + 6, 3), np.float32)
+    xyz[0:2 * n:2, 0], xyz[0:2 * n:2, 1] = 0.9 * np.cos(ang), 0.9 * np.sin(ang)
+    xyz[1:2 * n:2, 0], xyz[1:2 * n:2, 1] = -0.9 * np.cos(ang), -0.9 * np.sin(ang)
+    xyz[2 * n + 0] = (-300.0, -0.3, 0); xyz[2 * n + 1] = (280.0, 0.4, 0)
+    xyz[2 * n + 2] = (np.nan, 0, 0); xyz[2 * n + 3] = (0.5, 0.5, 0)
+    xyz[2 * n + 4] = (-9000.0, 0.1, 0); xyz[2 * n + 5] = (9000.0, 0.2, 0)
+    rgb = (S.uniform01(3, 3 * (2 * n + 6)).reshape(-1, 3)).astype(np.float32)
+    v = S.pack_vertices(xyz, rgb)
+    idx = np.arange(2 * n + 6, dtype=np.int64)
+    W, H = 500, 300
+    ref_c, ref_d, st, rc = oracle.render(v, idx, S.identity(), W, H, RL, primitive_type=1)
+    assert rc == 0 and st.triangles_skipped == 2
+    with swr.Context() as ctx:
+        c, d = ctx.render(v, idx, S.identity(), W, H, RL, primitive_type=1)
+        assert_same(c, d, ref_c, ref_d, "lines through one point")
+        for bad_flags, prim in ((RL, 0), (RL, 2), (RL | 1, 0)):
+            with pytest.raises(swr.SwrError):
+                ctx.render(v, idx[:6], S.identity(), W, H, bad_flags, primitive_type=prim)
+        with pytest.raises(swr.SwrError):
+            ctx.render(v, idx[:3], S.identity(), W, H, RL, primitive_type=1)       # odd index count (:209)
+    color = np.zeros((H, W, 4), dtype=np.uint8)
+    depth = np.zeros((H, W), dtype=np.float32)
+    with swr.Context(0, device_count=3) as ctx:
+        c, d = ctx.render(v, idx, S.identity(), W, H, RL, primitive_type=1)
+        assert_same(c, d, ref_c, ref_d, "lines on 3 bands of one context")
+    for k in range(4):
+        r0, r1 = swr.band_rows(H, 4, k)
+        with swr.Context() as ctx:
+            ctx.scene_upload(v, idx)
+            ctx.target_set(W, H, r0, r1)
+            ctx.draw(S.identity(), RL, primitive_type=1)
+            ctx.read_color(color)
+            ctx.read_depth(depth)
+    assert_same(color, depth, ref_c, ref_d, "lines, 4 band contexts")
 
 
 # ---- caller side: the app's frame loop (SURVEY.md §8(f) rank 4) ----------------------------------
@@ -613,45 +725,48 @@ def test_stream_order_is_invisible_with_ties_and_nonfinite_vertices(gpu_ctx, ora
         assert_same(c, d, ref_c, ref_d, f"duplicates flags={flags}")
 
 
-@pytest.mark.parametrize("env", [{"SWR_SORT": "-1"}, {"SWR_SORT": "0", "SWR_CULL": "2"}, {"SWR_CULL": "0"},
-                                 {"SWR_BIN_MODE": "exact", "SWR_SORT": "-1"}, {"SWR_BIN_MODE": "exact", "SWR_PIPELINE": "0"}],
-                         ids=["no-reorder(>=2^24 path)", "index-order+forced-cull", "no-cull",
-                              "exact-bins+no-reorder", "exact-bins+no-pipelining"])
-def test_stream_modes_in_a_child_process(env):
-    """The library reads SWR_SORT / SWR_CULL once: exercise the other modes in a child process.  SWR_SORT=-1 is the
-    path scenes of 2^24 primitives or more take (slot == index, nothing in GeomRec.flags); SWR_CULL=2 runs the cull
-    pass on whole-framebuffer targets too (off-screen groups)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    code = r"""
-import sys, numpy as np
-sys.path.insert(0, %r)
-import swr_amd
-from oracle import oracle
-S = swr_amd.scenes
-with swr_amd.Context() as ctx:
-    for flags in (0, 1, 4):
-        s = S.random_soup(5000, 500, 400, 0xABC + flags, r_ndc=0.08, margin=1.7)     # plenty off-screen
-        m = S.app_transform(0.8, scale=1.2)
-        if flags == 4:
-            rc, rd, _, code = oracle.render_metal(s.vertices, s.indices, m, 500, 400)
-        else:
-            rc, rd, _, code = oracle.render(s.vertices, s.indices, m, 500, 400, flags | oracle.TINV_PER_TRIANGLE)
-        c = np.zeros((400, 500, 4), np.uint8); d = np.zeros((400, 500), np.float32)
-        ctx.scene_upload(s.vertices, s.indices)
-        for k in range(3):
-            r0, r1 = swr_amd.band_rows(400, 3, k)
-            ctx.target_set(500, 400, r0, r1); ctx.draw(m, flags); ctx.read_color(c); ctx.read_depth(d)
-        assert code == 0 and np.array_equal(c, rc) and d.tobytes() == rd.tobytes(), ("bands", flags)
-        c, d = ctx.render(s.vertices, s.indices, m, 500, 400, flags)
-        assert np.array_equal(c, rc) and d.tobytes() == rd.tobytes(), ("full", flags)
-print("child ok")
-""" % root
-    out = subprocess.run([sys.executable, "-c", code], env={**os.environ, **env}, capture_output=True, text=True,
-                         timeout=300)
-    assert out.returncode == 0 and "child ok" in out.stdout, out.stdout[-2000:] + out.stderr[-2000:]
+@pytest.mark.parametrize("hooks", [{"order": -1}, {"order": 0}, {"cull": 0}, {"binmode": 1, "order": -1}, {"binmode": 1, "pipeline": 0},
+                                   {"k32": 0}, {"insort": 0}, {"binmode": 1, "insort": 0}, {"binmode": 3, "k32": 0}],
+                         ids=["no-reorder(>=2^24 path)", "index-order", "no-cull", "exact-bins+no-reorder", "exact-bins+no-pipelining",
+                              "64-bit-depth-keys", "k_sort_bins-for-depth-frames", "exact-bins+k_sort_bins", "atomic-bins+64-bit-keys"])
+def test_code_paths_forced_by_debug_hooks(swr, oracle, hooks):
+    """swr_debug_set (until round 4: environment variables read once, exercised in child processes): the paths the library
+    would otherwise only take for other scenes — stream order -1 is what scenes of 2^24 primitives or more get (slot == index,
+    nothing in GeomRec.flags) — rendered on 3 bands and on the whole target, four rule sets, against the oracle."""
+    B = swr.binding
+    S = swr.scenes
+    key = {"order": B.DEBUG_STREAM_ORDER, "cull": B.DEBUG_CULL, "binmode": B.DEBUG_BIN_MODE, "k32": B.DEBUG_DEPTH_KEYS32,
+           "insort": B.DEBUG_RASTER_SORT}
+    with swr.Context() as ctx:
+        for k, v in hooks.items():
+            if k == "pipeline":
+                ctx.pipeline_enable(bool(v))
+            else:
+                ctx.debug_set(key[k], v)
+        for flags in (0, 1, 3, 4):
+            s = S.random_soup(5000, 500, 400, 0xABC + flags, r_ndc=0.08, margin=1.7)     # plenty off-screen
+            m = S.app_transform(0.8, scale=1.2)
+            if flags == 4:
+                rc, rd, _, code = oracle.render_metal(s.vertices, s.indices, m, 500, 400)
+            else:
+                rc, rd, _, code = oracle.render(s.vertices, s.indices, m, 500, 400, flags | oracle.TINV_PER_TRIANGLE)
+            assert code == 0
+            c = np.zeros((400, 500, 4), np.uint8); d = np.zeros((400, 500), np.float32)
+            ctx.scene_upload(s.vertices, s.indices)
+            for k in range(3):
+                r0, r1 = swr.band_rows(400, 3, k)
+                ctx.target_set(500, 400, r0, r1); ctx.draw(m, flags)
+                if not flags & NC:
+                    ctx.read_color(c)
+                ctx.read_depth(d)
+            assert (flags & NC or np.array_equal(c, rc)) and d.tobytes() == rd.tobytes(), ("bands", flags)
+            c2, d2 = ctx.render(s.vertices, s.indices, m, 500, 400, flags)
+            assert (flags & NC or np.array_equal(c2, rc)) and d2.tobytes() == rd.tobytes(), ("full", flags)
+    with swr.Context() as ctx:
+        with pytest.raises(swr.SwrError):
+            ctx.debug_set(99, 0)
+        with pytest.raises(swr.SwrError):
+            ctx.debug_set(B.DEBUG_BIN_MODE, 7)
 
 
 def test_metal_rules_full_size_and_wide_divider_range(gpu_ctx, oracle, swr):
@@ -805,3 +920,26 @@ def test_large_triangles_join_the_bins_at_the_sort(swr, oracle, bands):
                     assert d.tobytes() == rd.tobytes(), f"{scene.name} flags={flags} frame {frame}: depth"
                     if not (flags & NC):
                         assert np.array_equal(ctx.read_color(), rc), f"{scene.name} flags={flags} frame {frame}: colour"
+
+
+@pytest.mark.parametrize("flags", [0, DT, DT | NC, 4])
+def test_affine_transforms_skip_the_divide(gpu_ctx, oracle, swr, flags):
+    """A transform whose last row is (0, 0, 0, 1) makes w exactly 1 (Renderer.swift:160-162): k_bin<.., AFF> skips the nine
+    divisions per triangle; rotations / shears / non-uniform scales / translations, a -0 in the last row, non-finite vertices and
+    a last row that is ALMOST (0, 0, 0, 1) (the dividing kernel again) must all match the oracle bit for bit."""
+    s = swr.scenes.random_soup(4000, 700, 500, 97, r_ndc=0.05, flags=flags, margin=1.0)
+    s.vertices[::97, 0] = np.inf
+    s.vertices[5::89, 2] = np.nan
+    c, sn = np.cos(0.7), np.sin(0.7)
+    rows = np.array([[0.9 * c, -1.1 * sn, 0.05, 0.03], [0.9 * sn, 1.1 * c, -0.02, -0.04], [0.1, 0.2, 0.7, 0.1], [0, 0, 0, 1]], dtype=np.float32)
+    for last in ((0, 0, 0, 1), (-0.0, 0, -0.0, 1), (0, 0, 1e-3, 1), (0, 0, 0, 1.0000001)):
+        m = rows.copy()
+        m[3] = last
+        s.transform = np.ascontiguousarray(m.T).reshape(16)
+        if flags == 4:
+            rc_c, rc_d, _, rc = oracle.render_metal(s.vertices, s.indices, s.transform, s.width, s.height)
+            assert rc == 0
+            cc, dd = gpu_ctx.render(s.vertices, s.indices, s.transform, s.width, s.height, flags)
+            assert_same(cc, dd, rc_c, rc_d, f"metal rules, last row {last}")
+        else:
+            check(gpu_ctx, oracle, s, flags, f"flags {flags}, last row {last}")

@@ -182,17 +182,18 @@ def crowded_scene(swr, ntri=20000):
 
 
 @pytest.mark.parametrize("bins", ["fixed", "exact"])
-def test_bin_overflow_is_repaired_or_reported(swr, oracle, monkeypatch, bins):
+def test_bin_overflow_is_repaired_or_reported(swr, oracle, bins):
     """Both bin layouts: k_bin's fixed tile regions (a crowded tile overflows its region) and the exact-size bins of the
     four-kernel path (more (triangle,tile) pairs than the list holds)."""
     if bins == "exact":
-        monkeypatch.setenv("SWR_BIN_MODE", "exact")
         s = big_scene(swr)
     else:
         s = crowded_scene(swr)
     rc_c, rc_d, _, _ = oracle.render(s.vertices, s.indices, s.transform, s.width, s.height, DT | NC | oracle.TINV_PER_TRIANGLE)
     # (1) draw + present + wait: the overflowing frame is redrawn with grown bins and copied again
     with swr.Context() as ctx:
+        if bins == "exact":
+            ctx.debug_set(swr.binding.DEBUG_BIN_MODE, swr.binding.BIN_MODE_EXACT)
         ctx.scene_upload(s.vertices, s.indices)
         ctx.target_set(s.width, s.height)
         d = swr.HostImage((s.height, s.width), np.float32)
@@ -205,6 +206,8 @@ def test_bin_overflow_is_repaired_or_reported(swr, oracle, monkeypatch, bins):
     # (2) an un-waited burst of PRESENTED frames: the earlier overflowing frame was rastered empty and copied to the
     # host like that -> reported once, bins grown, the last frame repaired
     with swr.Context() as ctx:
+        if bins == "exact":
+            ctx.debug_set(swr.binding.DEBUG_BIN_MODE, swr.binding.BIN_MODE_EXACT)
         ctx.scene_upload(s.vertices, s.indices)
         ctx.target_set(s.width, s.height)
         d = swr.HostImage((s.height, s.width), np.float32)
@@ -222,6 +225,8 @@ def test_bin_overflow_is_repaired_or_reported(swr, oracle, monkeypatch, bins):
         d.free()
     # (2b) the same burst without any present: nobody can have seen the empty frame -> no error, last frame repaired
     with swr.Context() as ctx:
+        if bins == "exact":
+            ctx.debug_set(swr.binding.DEBUG_BIN_MODE, swr.binding.BIN_MODE_EXACT)
         ctx.scene_upload(s.vertices, s.indices)
         ctx.target_set(s.width, s.height)
         ctx.draw(s.transform, DT | NC)
@@ -230,6 +235,8 @@ def test_bin_overflow_is_repaired_or_reported(swr, oracle, monkeypatch, bins):
         same(None, ctx.read_depth(), None, rc_d, "burst without presents")
     # (3) the same through a group and swr_render
     with swr.Context(0, device_count=2) as ctx:
+        if bins == "exact":
+            ctx.debug_set(swr.binding.DEBUG_BIN_MODE, swr.binding.BIN_MODE_EXACT)
         _, d = ctx.render(s.vertices, s.indices, s.transform, s.width, s.height, DT | NC)
         same(None, d, None, rc_d, "overflow inside a group")
 

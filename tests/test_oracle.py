@@ -316,6 +316,84 @@ def test_line_primitive_only_clears(oracle, swr):
     assert oracle.render(s.vertices, s.indices, s.transform, 32, 32, 0, primitive_type=9)[3] == -5
 
 
+def _lines_numpy(vertices, indices, transform, W, H, max_steps=1 << 20):
+    """SWR_FLAG_REAL_LINES read directly from the source text: endpoints as draw(vertices:) truncates them (Renderer.swift:298-299),
+    then draw(line:with:in:) (:405-419) — float steps, ACCUMULATED float x / y, rounded() half away from zero, `steps` pixels."""
+    F = np.float32
+    ref = np.zeros((H, W, 4), dtype=np.uint8)
+    M = np.asarray(transform, F).reshape(4, 4)
+    idx = np.asarray(indices).reshape(-1, 2)
+    q = lambda t: int(np.fmin(np.fmax(F(t), F(0)), F(1)) * F(255))
+    for a, b in idx:
+        e = []
+        for i in (a, b):
+            v = vertices[i]
+            r = M[0] * v[0]; r = r + M[1] * v[1]; r = r + M[2] * v[2]; r = r + M[3] * F(1)
+            with np.errstate(all="ignore"):
+                sx = (r[0] / r[3] * F(0.5) + F(0.5)) * F(W)
+                sy = (r[1] / r[3] * F(-0.5) + F(0.5)) * F(H)
+            e.append((sx, sy))
+        if not all(abs(float(c)) < 2.0 ** 30 for p in e for c in p):      # Swift's Int(NaN / huge) would trap: skipped
+            continue
+        (x0, y0), (x1, y1) = [(int(p[0]), int(p[1])) for p in e]
+        dx, dy = x1 - x0, y1 - y0
+        steps = max(abs(dx), abs(dy))
+        if steps == 0 or steps > max_steps:
+            continue
+        xs, ys = F(dx) / F(steps), F(dy) / F(steps)
+        xseq = np.add.accumulate(np.concatenate([[F(x0)], np.full(steps - 1, xs, F)]), dtype=F)      # x += xStep, sequentially
+        yseq = np.add.accumulate(np.concatenate([[F(y0)], np.full(steps - 1, ys, F)]), dtype=F)
+        rnd = lambda t: np.where(t >= 0, np.floor(t + F(0.5)), np.ceil(t - F(0.5))).astype(np.int64)   # exact for |t| < 2^22
+        px, py = rnd(xseq.astype(np.float64)), rnd(yseq.astype(np.float64))
+        ok = (px >= 0) & (px < W) & (py >= 0) & (py < H)
+        va = vertices[a]
+        ref[py[ok], px[ok]] = (q(va[6]), q(va[5]), q(va[4]), 255)
+    return ref
+
+
+def test_real_lines_match_a_direct_numpy_reading(oracle, swr):
+    """Opt-in .line (SWRO_REAL_LINES = SWR_FLAG_REAL_LINES): the C oracle against a NumPy reading of Renderer.swift:405-419."""
+    S = swr.scenes
+    s = S.random_soup(300, 160, 120, 77, r_ndc=0.5, margin=1.3)        # endpoints on and off the screen
+    idx = s.indices[:400]
+    for m in (s.transform, S.app_transform(0.6, scale=1.1)):
+        c, d, st, rc = oracle.render(s.vertices, idx, m, 160, 120, oracle.REAL_LINES, primitive_type=1)
+        assert rc == 0 and np.isposinf(d).all() and st.fragments > 1000
+        assert np.array_equal(c, _lines_numpy(s.vertices, idx, m, 160, 120))
+    # the default stays the reference's empty stub
+    c, _, st, rc = oracle.render(s.vertices, idx, s.transform, 160, 120, 0, primitive_type=1)
+    assert rc == 0 and (c == 0).all() and st.fragments == 0
+
+
+def test_real_lines_known_answers(oracle, swr):
+    """Hand-derived from Renderer.swift:405-419 on a 16 x 8 target (NDC -> screen: x = (nx/2 + 1/2) * 16, y = (-ny/2 + 1/2) * 8)."""
+    S = swr.scenes
+
+    def draw(p0, p1, col=(1.0, 0.5, 0.25)):
+        # screen (sx, sy) -> NDC
+        ndc = lambda p: ((p[0] / 16.0) * 2 - 1, -((p[1] / 8.0) * 2 - 1), 0.5)
+        v = S.pack_vertices(np.array([ndc(p0), ndc(p1)], np.float32), np.array([col, (0, 0, 1)], np.float32))
+        c, _, _, rc = oracle.render(v, np.array([0, 1], np.int64), S.identity(), 16, 8, oracle.REAL_LINES, primitive_type=1)
+        assert rc == 0
+        ys, xs = np.nonzero(c[..., 3])
+        return sorted(zip(xs.tolist(), ys.tolist())), c
+    # horizontal, left to right: steps = 5, pixels x = 2..6 (the end point 7 is NOT plotted), colour of the FIRST vertex
+    px, c = draw((2.5, 3.5), (7.5, 3.5))
+    assert px == [(2, 3), (3, 3), (4, 3), (5, 3), (6, 3)] and tuple(c[3, 2]) == (63, 127, 255, 255)
+    # right to left: starts at the first vertex, x = 7..3
+    assert draw((7.5, 3.5), (2.5, 3.5))[0] == [(3, 3), (4, 3), (5, 3), (6, 3), (7, 3)]
+    # a diagonal with slope 1/2: steps = 4, y advances by 0.5 and rounds half away from zero: 1, 1.5 -> 2, 2, 2.5 -> 3
+    assert draw((1.2, 1.7), (5.9, 3.1))[0] == [(1, 1), (2, 2), (3, 2), (4, 3)]
+    # both endpoints in one pixel: steps = 0, nothing drawn
+    assert draw((4.1, 4.1), (4.9, 4.9))[0] == []
+    # an odd index count is an error (verticesCount = 2, :183-184, :209); a non-finite endpoint skips the line
+    s = S.random_soup(4, 16, 8, 1)
+    assert oracle.render(s.vertices, s.indices[:3], s.transform, 16, 8, oracle.REAL_LINES, primitive_type=1)[3] == -2
+    s.vertices[0, 0] = np.nan
+    c, _, st, rc = oracle.render(s.vertices, s.indices[:2], s.transform, 16, 8, oracle.REAL_LINES, primitive_type=1)
+    assert rc == 0 and (c == 0).all() and st.triangles_skipped == 1
+
+
 # ---- the Metal path's rules (SURVEY.md §A.3, §8(f) rank 1) ---------------------------------------
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_metal_rules_c_equals_numpy(oracle, swr, seed):

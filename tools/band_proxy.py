@@ -8,9 +8,15 @@ S = swr_amd.scenes
 sc = S.cfg4_soup()
 flags = sc.flags
 res = {}
+# test hooks for A/Bs: key=value arguments go to swr_debug_set (e.g. insort=0 k32=0 binmode=1)
+KEYS = {"order": 1, "cull": 2, "binmode": 3, "oneshot": 4, "k32": 5, "insort": 6}
+hooks = [a.split("=") for a in sys.argv[1:] if "=" in a]
+parts_arg = [int(x) for x in sys.argv[1:] if "=" not in x]
 with swr_amd.Context() as ctx:
+    for k, v in hooks:
+        ctx.debug_set(KEYS[k], int(v))
     ctx.scene_upload(sc.vertices, sc.indices)
-    for parts in ([int(x) for x in sys.argv[1:]] or (1, 2, 4, 8)):
+    for parts in (parts_arg or (1, 2, 4, 8)):
         worst = 0.0
         for k in sorted({0, parts // 2, parts - 1}):
             r0, r1 = swr_amd.band_rows(sc.height, parts, k)

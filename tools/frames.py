@@ -11,6 +11,10 @@ sc = {"cfg4": lambda: S.cfg4_soup(), "cfg5": lambda: S.cfg5_sponza_scale(), "cfg
       "big": lambda: S.random_soup(300, 1920, 1080, 91, r_ndc=1.5, flags=1, margin=0.5),
       "mid": lambda: S.random_soup(5000, 1920, 1080, 93, r_ndc=0.16, flags=1, margin=1.0)}[name]()
 with swr_amd.Context() as ctx:
+    # swr_debug_set hooks for A/Bs under the profiler: SWR_AB_HOOKS="insort=0 k32=0"
+    for kv in os.environ.get("SWR_AB_HOOKS", "").split():
+        k, v = kv.split("=")
+        ctx.debug_set({"order": 1, "cull": 2, "binmode": 3, "oneshot": 4, "k32": 5, "insort": 6}[k], int(v))
     ctx.scene_upload(sc.vertices, sc.indices)
     r0, r1 = 0, sc.height
     if len(sys.argv) > 4:

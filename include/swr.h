@@ -228,12 +228,13 @@ int swr_debug_fault(swr_context* ctx, int fault);
  *   SWR_DEBUG_STREAM_ORDER      1 (default) Morton-ordered triangle stream; 0 keep the caller's primitive order;
  *                               -1 behave as for scenes of >= 2^24 primitives (no reordering, slot == index)
  *   SWR_DEBUG_CULL              1 (default) per-band culling of 64-primitive groups; 0 off
- *   SWR_DEBUG_BIN_MODE          0 (default) chosen per scene / target; 1 exact-size bins (four-kernel chain);
- *                               2 fixed-stride bins (k_bin) also for bands of large scenes; 3 global-atomic binning fallback
+ *   SWR_DEBUG_BIN_MODE          0 (default) fixed-stride bins (the single-launch k_bin) wherever they can hold the scene, exact-size
+ *                               bins otherwise; 1 always exact-size bins (four-kernel chain); 2 = 0; 3 global-atomic binning fallback
  *   SWR_DEBUG_ONESHOT_MIN_TRIS  primitives from which a swr_render without a scene identity cuts its index copy in two
  *                               (default 2^18; minimum 64)
  *   SWR_DEBUG_DEPTH_KEYS32      1 (default) depth-only z-tested frames take 32-bit depth keys (k_raster_depth); 0 the 64-bit kernel
- *   SWR_DEBUG_RASTER_SORT       1 (default) such frames sort their bins inside the raster workgroups; 0 k_sort_bins launch */
+ *   SWR_DEBUG_RASTER_SORT       1 (default) such frames sort their bins inside the raster workgroups on small tile grids (thin
+ *                               bands), by a k_sort_bins launch on large ones; 0 always the launch; 2 always inside the raster */
 enum { SWR_DEBUG_STREAM_ORDER = 1, SWR_DEBUG_CULL = 2, SWR_DEBUG_BIN_MODE = 3, SWR_DEBUG_ONESHOT_MIN_TRIS = 4,
        SWR_DEBUG_DEPTH_KEYS32 = 5, SWR_DEBUG_RASTER_SORT = 6 };
 int swr_debug_set(swr_context* ctx, int key, int64_t value);

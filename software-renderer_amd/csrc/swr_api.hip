@@ -140,7 +140,7 @@ struct swr_context {
     int dbg_bin_mode = 0;               // 0 auto, 1 exact-size bins, 2 fixed-stride bins everywhere, 3 global-atomic fallback
     int64_t dbg_oneshot_min_tris = (int64_t)1 << 18;
     bool dbg_k32 = true;                // depth-only z-tested frames on 32-bit depth keys
-    bool dbg_insort = true;             // ... which sort their bins inside the raster workgroups
+    int dbg_insort = 1;                 // ... which sort their bins inside the raster workgroups: 0 never, 1 on small grids, 2 always
     // scene identity of swr_render (swr_render_pass.scene_id): what is resident
     uint64_t scene_id = 0;
     int64_t scene_nv = -1, scene_ni = -1;
@@ -209,6 +209,7 @@ struct swr_context {
     // while k_raster of frame N runs on `stream` (HBM-bound vs LDS/VALU-bound: they overlap well).
     struct Slot {
         DevBuf geo, geo_full, ranges, bins, bin_matrix;
+        DevBuf tinv;           // colour frames: 48-B shade record (T(), cf, z) of every binned triangle (k_bin -> the resolve of k_raster)
         DevBuf biglist;        // fixed-stride bins: the frame's deferred large triangles (k_bin -> k_sort_bins)
         DevBuf live;           // per binning workgroup: count + surviving stream-group ids (k_setup_hist -> k_fill_lds)
         DevBuf tilebuf;        // [CNT_WORDS counters][tiles tile_count][tiles+1 tile_start][tiles cursor]
@@ -500,12 +501,13 @@ int size_bins(swr_context* c) {
         c->sized_ntri = ntri; c->sized_tiles = tiles;
     }
 
-    // A band of a large scene (what one GPU of N renders, §7) bins faster with round 2's chain of three short kernels than
-    // with the one long k_bin, which shares the chip with the band's raster worse: worst band of N = 2 / 4 / 8 on one GPU
-    // 52.4 / 37.6 / 27.9 us per frame against 59.3 / 38-40 / 30.7 (profiles/r03/b_band_proxy_*); the whole 4K frame is
-    // the other way round (81.9 vs 84.0).  swr_debug_set(SWR_DEBUG_BIN_MODE, 2) forces k_bin.
-    const bool band_like = tiles < 3000 && ntri >= 200000 && c->dbg_bin_mode != 2;
-    const bool no_fixed = c->dbg_bin_mode == 1 || c->dbg_bin_mode == 3 || band_like;
+    // Bands of large scenes (what one GPU of N renders) took round 2's chain of three short binning kernels in round 3: the one
+    // long k_bin shared the chip with the band's raster worse.  With the perspective divide gone for affine transforms (k_bin
+    // <.., AFF>) and no k_sort_bins launch on thin depth-only bands (the raster sorts its own bins) it is the other way round:
+    // worst band of N = 2 / 4 / 8 on one GPU 47.1 / 29.3 / 24.5 us per frame against 52.8 / 35.7 / 26.3 with the chain
+    // (profiles/r04/band_binmode_ab.txt) — k_bin everywhere.  Colour frames: N = 2 / 4 equal, N = 8 32.9 (chain) vs 36.4.
+    // swr_debug_set(SWR_DEBUG_BIN_MODE, 1) forces the chain.
+    const bool no_fixed = c->dbg_bin_mode == 1 || c->dbg_bin_mode == 3;
     const uint32_t cmax = (c->fixed_allowed && !no_fixed) ? fixed_cap_max(ntri, tiles) : 0u;
     int rc;
     if (cmax) {
@@ -550,6 +552,7 @@ DeviceFrame make_frame(swr_context* c, int si, uint64_t frame, const float m[16]
     f.ntri = c->ni / 3;
     f.geo = (GeomRec*)sl.geo.p;
     f.geo_full = (GeomFull*)sl.geo_full.p;
+    f.tinv = nullptr;       // (set below, once the frame knows its target and material: frame_uses_shade_records)
     uint32_t* tb = (uint32_t*)sl.tilebuf.p;
     f.counters = tb;
     f.host_counters = c->h_pairs_dev + (frame % swr_context::PAIR_RING);   // word CNT_PAIRS (= 0) of this frame
@@ -593,6 +596,8 @@ DeviceFrame make_frame(swr_context* c, int si, uint64_t frame, const float m[16]
     f.tg = c->tg;
     memcpy(f.m, m, sizeof f.m);
     f.flags = flags;
+    // sparse colour frames under the CPU rules: the binning stage leaves a shade record per binned triangle for the resolve
+    if (frame_uses_shade_records(f)) f.tinv = (float4*)sl.tinv.p;
     return f;
 }
 
@@ -718,9 +723,13 @@ int enqueue_frame(swr_context* c) {
         const uint32_t redo = __atomic_load_n(&c->h_pairs[2 * swr_context::PAIR_RING + 1], __ATOMIC_RELAXED);
         if ((uint64_t)redo * 8u * 50u > (uint64_t)tiles_of(c->tg)) { c->k32_ok = false; f.k32 = 0; }
     }
-    // ... and such a frame sorts its bins inside the raster workgroups (the LDS the narrow keys leave free): no k_sort_bins
-    // launch — unless the frame defers triangles that cover hundreds of tiles, which k_sort_bins appends to the bins
-    if (c->dbg_insort && frame_uses_k32(f) && !f.defer_big && !f.skip_sort && sort_stream_mode < 0) { f.insort = 1; f.skip_sort = 1; }
+    // ... and on a small grid (a thin band: the frame is bound by its kernel chain, not by the chip) such a frame sorts its bins
+    // inside the raster workgroups, in the LDS the narrow keys leave free: no k_sort_bins launch — unless the frame defers
+    // triangles that cover hundreds of tiles, which k_sort_bins appends to the bins.  On a grid that fills the chip the launch
+    // is the cheaper place for the sort (swr_kernels.hip, raster_tile; profiles/r04/insort_ab.txt).
+    // (swr_debug_set SWR_DEBUG_RASTER_SORT: 0 never, 1 by grid size, 2 always)
+    const bool insort_grid = c->dbg_insort == 2 || (c->dbg_insort == 1 && tiles_of(c->tg) <= 1536);
+    if (insort_grid && frame_uses_k32(f) && !f.defer_big && !f.skip_sort && sort_stream_mode < 0) { f.insort = 1; f.skip_sort = 1; }
     const bool all = c->timing >= 2;
     if (f.ntri <= 0) { int rc = sync_streams(c); if (rc) return rc; pair_word(c, frame) = 0; }
     if (!f.fixed_bins) fill_word(c, frame) = 0;
@@ -979,6 +988,7 @@ int single_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vert
     for (auto& sl : c->slot) {
         if ((rc = ensure(c, sl.geo, (size_t)(index_count / 3) * sizeof(GeomRec)))) return rc;
         if ((rc = ensure(c, sl.geo_full, (size_t)(index_count / 3) * sizeof(GeomFull)))) return rc;
+        if ((rc = ensure(c, sl.tinv, (size_t)(index_count / 3) * 48))) return rc;
         if ((rc = ensure(c, sl.ranges, (size_t)(index_count / 3) * sizeof(uint2)))) return rc;
         if ((rc = ensure(c, sl.biglist, (size_t)1024 * 16))) return rc;
         if ((rc = ensure(c, sl.live, (size_t)((index_count / 3 + 63) / 64 + 2 * 1024 + 2) * 4))) return rc;   // [G <= 1024][1 + per]
@@ -1375,7 +1385,7 @@ void destroy_single(swr_context* c) {
                       &c->fillbuf[0], &c->fillbuf[1], &c->fillbuf[2], &c->fillbuf[3]};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
     for (auto& sl : c->slot) {
-        DevBuf* sb[] = {&sl.geo, &sl.geo_full, &sl.ranges, &sl.bins, &sl.bin_matrix, &sl.live, &sl.tilebuf, &sl.biglist};
+        DevBuf* sb[] = {&sl.tinv, &sl.geo, &sl.geo_full, &sl.ranges, &sl.bins, &sl.bin_matrix, &sl.live, &sl.tilebuf, &sl.biglist};
         for (DevBuf* b : sb) if (b->p) hipFree(b->p);
         if (sl.bin_done) hipEventDestroy(sl.bin_done);
         if (sl.ras_done) hipEventDestroy(sl.ras_done);
@@ -1905,8 +1915,8 @@ int swr_debug_set(swr_context* c, int key, int64_t value) {
             if (value < 0 || value > 1) break;
             c->dbg_k32 = value != 0; return SWR_OK;
         case SWR_DEBUG_RASTER_SORT:
-            if (value < 0 || value > 1) break;
-            c->dbg_insort = value != 0; return SWR_OK;
+            if (value < 0 || value > 2) break;
+            c->dbg_insort = (int)value; return SWR_OK;
         default:
             return fail(c, SWR_ERR_BAD_ARG, "swr_debug_set: unknown key %d", key);
     }

@@ -193,6 +193,8 @@ __global__ void k_validate_indices(const int64_t* __restrict__ idx, int64_t n, i
 }
 
 // swr_texture_upload: Pixel (b,g,r,a bytes) -> (r,g,b,a) floats, channel / 255.0f (IEEE division, once).
+// (A layout with the 2 x 2 texels of a bilinear fetch stored together, 48 B per texel and one read per shaded pixel, measured
+// 3 % slower on BASELINE config 5 textured: profiles/r04/texture_quads_ab.txt.)
 __global__ void k_texture_to_float(const uint32_t* __restrict__ bgra, int64_t n, float4* __restrict__ out) {
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -213,6 +215,7 @@ struct SetupArgs {
     int64_t ntri;
     GeomRec* geo;
     GeomFull* geo_full;
+    float4* tinv;           // colour frames under the CPU rules: a 48-B shade record (T(), cf, z) per binned triangle for the resolve; else NULL
     uint32_t* tile_count;
     uint2* ranges;
     Target tg;
@@ -279,7 +282,10 @@ __device__ __forceinline__ void decode_vertices(const GeomFull* __restrict__ ful
 // (AFF = the transform's last row is (0, 0, 0, 1) — identity, orthographic, any affine map: w is then exactly 1 for every
 // finite vertex (0*x + 0*y + 0*z + 1, :160) and x / 1 = x (:162), so the nine IEEE divisions per triangle are skipped; a
 // non-finite vertex makes sx / sy non-finite either way and the triangle is skipped either way.  Chosen by the host, k_bin only.)
-template <bool MT, bool AFF = false>
+// (TINV = a colour frame under the CPU rules: T() (:95-100) of every binned triangle is left in SetupArgs::tinv — once per
+// triangle here instead of once per new winner in every resolve thread, where four exact divisions were ~4.8 M of the colour
+// kernel's wave-instructions per cfg4 frame.  0 / 1 decided at compile time (k_bin), -1 = look at the pointer.)
+template <bool MT, bool AFF = false, int TINV = -1>
 __device__ __forceinline__ uint2 setup_triangle_r(const SetupArgs& a, int64_t p, const float4& xa, const float4& xb, const float4& xc);
 __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p, const float4& xa, const float4& xb, const float4& xc) {
     return a.metal ? setup_triangle_r<true>(a, p, xa, xb, xc) : setup_triangle_r<false>(a, p, xa, xb, xc);
@@ -289,7 +295,7 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
     return setup_triangle(a, p, a.tri_xyz[3 * p + 0], a.tri_xyz[3 * p + 1], a.tri_xyz[3 * p + 2]);
 }
 // ... with the corners already loaded (k_setup_hist fetches those of its next group while it works on this one)
-template <bool MT, bool AFF>
+template <bool MT, bool AFF, int TINV>
 __device__ __forceinline__ uint2 setup_triangle_r(const SetupArgs& a, int64_t p, const float4& xa, const float4& xb, const float4& xc) {
     uint2 range = make_uint2(RANGE_NONE_X, 0u);
     const uint32_t orig = a.reordered ? __float_as_uint(xa.w) : 0u;
@@ -385,6 +391,15 @@ __device__ __forceinline__ uint2 setup_triangle_r(const SetupArgs& a, int64_t p,
             int4* fp = reinterpret_cast<int4*>(a.geo_full + p);
             fp[0] = make_int4(ix[0], iy[0], ix[1], iy[1]);
             fp[1] = make_int4(ix[2], iy[2], 0, 0);
+        }
+        if (!MT && (TINV == 1 || (TINV < 0 && a.tinv != nullptr))) {
+            // what the resolve needs of the winning triangle besides its colours: T(), cf = float(C) + 0.5 (:89), the three z
+            float4 t;
+            tinv_of(ix[0], iy[0], ix[1], iy[1], ix[2], iy[2], t.x, t.y, t.z, t.w);      // the same function the raster's setup calls
+            float4* sr = a.tinv + 3 * p;
+            sr[0] = t;
+            sr[1] = make_float4((float)ix[2] + 0.5f, (float)iy[2] + 0.5f, sz[0], sz[1]);
+            sr[2] = make_float4(sz[2], 0.0f, 0.0f, 0.0f);
         }
     }
     if (binned)
@@ -770,7 +785,7 @@ __device__ __forceinline__ int tiles_of_box(const PixBox& b) {
     return b.x0 <= b.x1 ? (b.x1 / TILE_W - b.x0 / TILE_W + 1) * (b.y1 / TILE_H - b.y0 / TILE_H + 1) : 0;
 }
 
-template <int BT, bool MT, bool DEFER, bool AFF = false>
+template <int BT, bool MT, bool DEFER, bool AFF = false, bool TINV = false>
 // Register budget of the plain kernel: 56 VGPRs (tools/vgprs.sh) — with 58 the pipelined cfg4 frame measured 4 % slower (one of its waves has
 // to fit beside five raster waves of 88); neither launch bounds nor amdgpu_waves_per_eu make this hipcc keep it, the source does.
 __global__ __launch_bounds__(BT) void k_bin(BinArgs b) {
@@ -824,7 +839,7 @@ __global__ __launch_bounds__(BT) void k_bin(BinArgs b) {
             }
             uint2 r = make_uint2(RANGE_NONE_X, 0u);
             if (p < a.ntri) {
-                r = setup_triangle_r<MT, AFF>(a, p, xa, xb, xc);
+                r = setup_triangle_r<MT, AFF, TINV ? 1 : 0>(a, p, xa, xb, xc);
                 if (DEFER && tiles_of_box(unpack_box(r)) > BIN_BIG_TILES) {
                     const uint32_t e = atomicAdd(&b.fill[CNT_BIGLIST], 1u);
                     if (e < BIGLIST_CAP) {                           // (a full list: walked like any other)
@@ -1090,6 +1105,7 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_bins(uint32_t* __restrict
 struct RasterArgs {
     const GeomRec* geo;
     const GeomFull* geo_full;
+    const float4* tinv;         // colour frames under the CPU rules: 3 float4 per stream slot (T() | cf.x, cf.y, za, zb | zc), left by the binning stage
     const uint32_t* inv;        // [ntri] original primitive index -> stream slot (resolve; only when reordered)
     int reordered;              // bin entries are stream slots; keys carry the original index from GeomRec.flags
     const float4* tri_rgb;      // [3*ntri] vertex colours per slot corner, de-indexed at upload (r,g,b,v)
@@ -1108,7 +1124,6 @@ struct RasterArgs {
     uint32_t* host_pairs;   // fixed-stride bins: pinned host words for the frame's pair total, its largest fill (the overflow
     uint32_t* host_fill;    // test) and the same for the host's sort heuristic — k_bin leaves them in device counters
     uint32_t* host_max;
-    int slot_bits24;    // every stream slot fits 24 bits (it can ride in a record's flag word)
     int insort;         // 32-bit keys: the bins are unsorted and tagged (no k_sort_bins ran): the workgroup sorts its bin in LDS
     int vs_log;         // 2^vs_log workgroups per tile, each owning TILE_H >> vs_log of its rows (small grids, see launch_raster)
     uint32_t* redo_dev; // k_raster_depth: tiles (one in REDO_SAMPLE) that had to be rastered again with 64-bit keys, since the last launch
@@ -1120,9 +1135,7 @@ constexpr int REDO_SAMPLE = 8;
 // 64-bit visibility keys (orderable depth << 32 | primitive, or ~primitive without z-test): every frame that needs the
 // winner's identity — colour frames, painter's order, the Metal rules.
 constexpr int RASTER_QCAP = 128;         // ring entries per wave (see raster_tile)
-constexpr int RASTER_SORT_SEG = 1024;    // bin entries a raster workgroup sorts in its own LDS (fuller bins stay unsorted; four per
-                                         // thread: eight cost the kernel 5 VGPRs at its start, over the budget of 88)
-constexpr int RASTER_SORT_WORDS = 2048;  // LDS words behind that: the sorted entries, or the records of sorted positions 256..511
+constexpr int RASTER_SORT_SEG = 1024;    // bin entries a raster workgroup can sort in its own LDS (fuller bins stay unsorted)
 struct alignas(16) RasterLds64 {
     unsigned long long keys[TILE_W * TILE_H];
     float4 tabAB[2 * RASTER_THREADS];    // per triangle of the batch: (t00, t01, t10, t11) | (za, zb, zc, (C.x - X0) | (C.y - Y0) << 16)
@@ -1142,10 +1155,10 @@ struct alignas(16) RasterLds32 {
     uint32_t queue[RASTER_THREADS / 64][RASTER_QCAP];
     uint32_t next_chunk;
     uint32_t redo;                       // a thread of the resolve met a key the 64-bit path has to decide
-    // The 8 KB the narrow keys leave free hold the tile's bin, counting-sorted by size class by the workgroup itself
-    // (raster_tile, INSORT): such frames need no k_sort_bins launch in front of the raster.
+    // Part of what the narrow keys leave free holds the tile's bin, counting-sorted by size class by the workgroup itself
+    // (raster_tile, insort — small grids only): such frames need no k_sort_bins launch in front of the raster.
     uint32_t cls_cnt[64];
-    uint32_t sorted[RASTER_SORT_WORDS];
+    uint32_t sorted[RASTER_SORT_SEG];
 };
 static_assert(sizeof(RasterLds32) <= sizeof(RasterLds64), "the 32-bit path must not need more LDS than the 64-bit one (5 workgroups per CU)");
 // The atomic is ds_min_f32.  What the LDS does with the special values was measured on the device
@@ -1411,57 +1424,29 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
     if (tid == 0) next_chunk = RASTER_THREADS / 64;
     const uint32_t slot0 = chunk * csz + (uint32_t)lane;
     const bool have0 = (uint32_t)lane < csz && slot0 < m;
-    // 32-bit keys: the workgroup sorts its bin by size class itself (what k_sort_bins does in a launch of its own for the
-    // other kernels), in the LDS the narrow keys leave free: entries -> registers, class counts by returning LDS atomics,
-    // every wave scans the 33 counts for itself (no barrier for the prefix), scatter in class order, heaviest first.  Two
-    // barriers more than the clear needs.  Row-split tiles (every wave walks every chunk) do not care about the order and are
-    // left alone.
-    //  * Bins of up to 512 entries (cfg4: 365 on average): the RECORDS travel too.  Every thread gathers the records of its
-    //    two entries right behind the entries — the two round trips to memory overlap the clear and the first barrier, as the
-    //    prefetch of the first chunk always did — and writes them to their sorted positions: positions 0..255 (the four waves'
-    //    first chunks, read back right after the last barrier, each wave from its own slice) into the per-triangle tables,
-    //    which nothing uses before the first chunk's setup; positions 256..511 into the 8 KB the narrow keys leave free.  The
-    //    chunks then read entry and record from LDS; nothing is gathered after the sort.  (Entries only, records gathered
-    //    after the sort: k_raster_depth 64 -> 68 us — one more round trip exposed per workgroup.)  The stream slot travels in
-    //    bits 8..31 of the record's flag word, where the 64-bit keys keep the original index.
-    //  * Fuller bins, up to 1 024 entries: entries only.
+    // 32-bit keys, small grids (a thin band: what one GPU of eight renders): the workgroup sorts its bin by size class itself
+    // — what k_sort_bins does in a launch of its own — in the LDS the narrow keys leave free: entries -> registers, class counts
+    // by returning LDS atomics, every wave scans the 33 counts for itself (no barrier for the prefix), entries -> LDS in class
+    // order, heaviest first.  Two barriers more than the clear needs; the chunks then take their entries from LDS.  A frame of
+    // a thin band is bound by its kernel chain (sort 5 us + a 5 us launch gap in front of a 21 us raster), so the launch
+    // saved is worth more there than the sort costs inside the raster: worst band of 8, 27.8 -> 26.0-26.4 us per frame.  On a
+    // grid that fills the chip it is the other way round — a raster workgroup holds 27 KB of LDS and 87 registers per thread
+    // while it waits for its own sort's round trip, k_sort_bins' light workgroups hide theirs behind each other:
+    // k_raster_depth alone 64.2 -> 68.5 us, the cfg4 frame 0.0775 -> 0.0792 ms — so the host asks for it on small grids only
+    // (profiles/r04/insort_ab.txt; also measured there: wave 0 alone sorting while the others clear — same 68.5 —, and the
+    // RECORDS exchanged through LDS too so that nothing is gathered after the sort — 72.7).  Row-split tiles (every wave walks
+    // every chunk) do not care about the order and are left alone.
     constexpr int SORT_PER = RASTER_SORT_SEG / RASTER_THREADS;
-    constexpr int REC_PER = 2;                                  // entries per thread whose records are exchanged
-    constexpr uint32_t REC_MAX = REC_PER * RASTER_THREADS;
-    bool insort = false, inrec = false;
+    bool insort = false;
     uint32_t s_ent[K32 ? SORT_PER : 1];
-    int4 s_r0[K32 ? REC_PER : 1];
-    float4 s_r1[K32 ? REC_PER : 1];
-    // record of sorted position sp: (tabA[sp], tabB[sp]) below 256, the pair 2 (sp - 256) of `sorted` from there on
-    uint32_t* sorted_base = nullptr;
-    if constexpr (K32) sorted_base = L.sorted;
-    auto rec_q0 = [&](uint32_t sp) -> int4* {
-        return sp < (uint32_t)RASTER_THREADS ? reinterpret_cast<int4*>(tabA) + sp : reinterpret_cast<int4*>(sorted_base) + 2 * (sp - RASTER_THREADS);
-    };
-    auto rec_q1 = [&](uint32_t sp) -> float4* {
-        return sp < (uint32_t)RASTER_THREADS ? tabB + sp : reinterpret_cast<float4*>(sorted_base) + 2 * (sp - RASTER_THREADS) + 1;
-    };
     if constexpr (K32) {
-        static_assert(sizeof(L.sorted) >= (size_t)(REC_MAX - RASTER_THREADS) * 32, "the records of positions 256.. fit the sorted region");
         insort = a.insort != 0 && a.tag_class != 0 && !rowsplit && m <= (uint32_t)RASTER_SORT_SEG;
-        inrec = insort && m <= REC_MAX && a.slot_bits24 != 0;
         if (insort) {
             if (tid < 64) L.cls_cnt[tid] = 0u;
 #pragma unroll
             for (int k = 0; k < SORT_PER; k++) {
                 const uint32_t i = (uint32_t)(tid + k * RASTER_THREADS);
                 s_ent[k] = i < m ? a.bins[b0 + i] : 0u;
-            }
-            if (inrec) {
-#pragma unroll
-                for (int k = 0; k < REC_PER; k++) {
-                    const uint32_t pr = s_ent[k] & bin_mask;
-                    s_r0[k] = make_int4(0, 0, 0, 0); s_r1[k] = make_float4(0, 0, 0, 0);
-                    if ((uint32_t)(tid + k * RASTER_THREADS) < m) {
-                        s_r0[k] = reinterpret_cast<const int4*>(a.geo + pr)[0];
-                        s_r1[k] = reinterpret_cast<const float4*>(a.geo + pr)[1];
-                    }
-                }
             }
         }
     }
@@ -1493,37 +1478,17 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
             const int cl = NUM_CLASSES - 1 - lane;
             const uint32_t cv = cl >= 0 ? L.cls_cnt[cl] : 0u;
             const uint32_t cbase = (uint32_t)wave_incl_add((int)cv) - cv;
-            if (inrec) {
 #pragma unroll
-                for (int k = 0; k < REC_PER; k++) {
-                    const uint32_t cls = s_ent[k] >> CLASS_SHIFT;
-                    const uint32_t sp = (uint32_t)__shfl((int)cbase, (int)(NUM_CLASSES - 1 - cls)) + s_pos[k];
-                    if ((uint32_t)(tid + k * RASTER_THREADS) < m) {
-                        const uint32_t pr = s_ent[k] & bin_mask;
-                        s_r1[k].w = __uint_as_float((__float_as_uint(s_r1[k].w) & ((1u << GEOM_ORIG_SHIFT) - 1u)) | (pr << GEOM_ORIG_SHIFT));
-                        *rec_q0(sp) = s_r0[k];
-                        *rec_q1(sp) = s_r1[k];
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int k = 0; k < SORT_PER; k++) {
-                    const uint32_t cls = s_ent[k] >> CLASS_SHIFT;
-                    const uint32_t base = (uint32_t)__shfl((int)cbase, (int)(NUM_CLASSES - 1 - cls));
-                    if ((uint32_t)(tid + k * RASTER_THREADS) < m) L.sorted[base + s_pos[k]] = s_ent[k] & bin_mask;
-                }
+            for (int k = 0; k < SORT_PER; k++) {
+                const uint32_t cls = s_ent[k] >> CLASS_SHIFT;
+                const uint32_t base = (uint32_t)__shfl((int)cbase, (int)(NUM_CLASSES - 1 - cls));
+                if ((uint32_t)(tid + k * RASTER_THREADS) < m) L.sorted[base + s_pos[k]] = s_ent[k] & bin_mask;
             }
             __syncthreads();
             if (have0) {
-                if (inrec) {
-                    q0_pre = *rec_q0(slot0);
-                    q1_pre = *rec_q1(slot0);
-                    prim_pre = __float_as_uint(q1_pre.w) >> GEOM_ORIG_SHIFT;
-                } else {
-                    prim_pre = L.sorted[slot0];
-                    q0_pre = reinterpret_cast<const int4*>(a.geo + prim_pre)[0];
-                    q1_pre = reinterpret_cast<const float4*>(a.geo + prim_pre)[1];
-                }
+                prim_pre = L.sorted[slot0];
+                q0_pre = reinterpret_cast<const int4*>(a.geo + prim_pre)[0];
+                q1_pre = reinterpret_cast<const float4*>(a.geo + prim_pre)[1];
             }
         }
     }
@@ -1711,8 +1676,7 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
             const uint32_t e2 = chunk_next * csz + (uint32_t)lane;
             have_next = chunk_next < nchunks && (uint32_t)lane < csz && e2 < m;
             if constexpr (K32) {
-                if (have_next && inrec) prim_pre = e2;      // (the sorted position: entry and record are read from LDS below)
-                else if (have_next) prim_pre = insort ? L.sorted[e2] : a.bins[b0 + e2] & bin_mask;
+                if (have_next) prim_pre = insort ? L.sorted[e2] : a.bins[b0 + e2] & bin_mask;
             } else {
                 if (have_next) prim_pre = a.bins[b0 + e2] & bin_mask;
             }
@@ -1979,13 +1943,7 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
         }
         // the next chunk (wave-uniform, chosen by steal_next): its records, now that the bin entries have arrived
         chunk = chunk_next;
-        if (K32 && inrec) {
-            if (have_next) {    // (a stolen chunk: positions 256.. only — the first four chunks are the waves' own)
-                q0_pre = reinterpret_cast<const int4*>(sorted_base)[2 * (prim_pre - RASTER_THREADS)];
-                q1_pre = reinterpret_cast<const float4*>(sorted_base)[2 * (prim_pre - RASTER_THREADS) + 1];
-                prim_pre = __float_as_uint(q1_pre.w) >> GEOM_ORIG_SHIFT;
-            }
-        } else if (have_next) {
+        if (have_next) {
             q0_pre = reinterpret_cast<const int4*>(a.geo + prim_pre)[0];
             q1_pre = reinterpret_cast<const float4*>(a.geo + prim_pre)[1];
         }
@@ -2078,6 +2036,13 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
     // (NGX != 0: the launch chose — colour frames of SPARSE scenes, whose binning is short, take the joint walk: cfg5 0.198 -> 0.186 ms,
     // cfg3 0.0422 -> 0.0408; cfg4's colour frames, 245 triangles per tile, lose 7 % with it beside their long k_bin)
     constexpr int NG = NGX ? NGX : (EXT ? SWR_NG_EXT : (!COLOR ? SWR_NG_DEPTH : (METAL ? SWR_NG_METAL_COLOR : SWR_NG_COLOR)));
+    // Shade records (T(), cf and the three z of every binned triangle, 48 B, written by the binning stage of colour frames:
+    // setup_triangle_r, TINV) instead of the GeomRec gather + vertex decode + the four exact divisions of T() per new winner.
+    // Only the SPARSE colour kernels (NGX == 2: fewer than 64 primitives per tile, BASELINE configs 2, 3, 5): cfg5 0.1848 ->
+    // 0.1744 ms.  On cfg4's colour frames (245 primitives per tile) the extra 48 MB per working set written beside the raster and
+    // gathered by it made EVERY kernel of the pipelined frame slower (k_bin 83 -> 130-157 us, k_raster 132 -> 172 under the
+    // tracer; the frame 0.119 -> 0.168 ms) although the stages alone barely moved: profiles/r04/shade_records_ab.txt.
+    constexpr bool SHREC = COLOR && !METAL && !EXT && NGX == 2;
     static_assert(NG == 1 || NG == 2, "a thread owns two groups");
     for (int i0 = tid; VAR != 8 && VAR != 10 && VAR != 11 && i0 < TILE_W * TILE_H / 4; i0 += NG * RASTER_THREADS) {
         int ly[NG], lx[NG], y[NG], x[NG];
@@ -2129,13 +2094,29 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                     cached_prim[g] = prim[g];
                     // colour frames hold the winners' stream slots in LDS (above); depth-only: only the rare d == 0 winner
                     slot[g] = !a.reordered ? prim[g] : (want_color ? slots[ly[g] * TILE_W + lx[g] + k] : a.inv[prim[g]]);
-                    g0[g] = reinterpret_cast<const int4*>(a.geo + slot[g])[0];
-                    q3[g] = reinterpret_cast<const float4*>(a.geo + slot[g])[1];
+                    if (SHREC) {
+                        // the winner's shade record, left by the binning stage (setup_triangle_r, TINV): T(), cf, za, zb | zc
+                        const float4* sr = a.tinv + 3 * (size_t)slot[g];
+                        q2[g] = sr[0];
+                        const float4 s1 = sr[1];
+                        cfx[g] = s1.x; cfy[g] = s1.y;
+                        q3[g] = make_float4(s1.z, s1.w, reinterpret_cast<const float*>(sr + 2)[0], 0.0f);
+                    } else {
+                        g0[g] = reinterpret_cast<const int4*>(a.geo + slot[g])[0];
+                        q3[g] = reinterpret_cast<const float4*>(a.geo + slot[g])[1];
+                    }
                     if (want_color) {
                         // vertex colours of a,b,c (RenderPass.vertices[RenderPass.indices[3p+k]].color), one 48-B record
-                        ca[g] = a.tri_rgb[3 * (size_t)slot[g] + 0];
-                        cb[g] = a.tri_rgb[3 * (size_t)slot[g] + 1];
-                        cc[g] = a.tri_rgb[3 * (size_t)slot[g] + 2];
+                        if (EXT) {
+                            ca[g] = a.tri_rgb[3 * (size_t)slot[g] + 0];
+                            cb[g] = a.tri_rgb[3 * (size_t)slot[g] + 1];
+                            cc[g] = a.tri_rgb[3 * (size_t)slot[g] + 2];
+                        } else {   // (lane 3 = the texture coordinate v: only the extended stage reads it — nine registers in flight, not twelve)
+                            const float* cp = reinterpret_cast<const float*>(a.tri_rgb + 3 * (size_t)slot[g]);
+                            ca[g] = make_float4(cp[0], cp[1], cp[2], 0.0f);
+                            cb[g] = make_float4(cp[4], cp[5], cp[6], 0.0f);
+                            cc[g] = make_float4(cp[8], cp[9], cp[10], 0.0f);
+                        }
                         if (EXT) {
                             na[g] = a.tri_nrm[3 * (size_t)slot[g] + 0];
                             nb[g] = a.tri_nrm[3 * (size_t)slot[g] + 1];
@@ -2146,13 +2127,14 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
             }
 #pragma unroll
             for (int g = 0; g < NG; g++) {
-                if (miss[g]) {
+                if (miss[g] && !SHREC) {
                     int vx[3], vy[3];
                     decode_vertices(a.geo_full, slot[g], g0[g], q3[g], vx, vy);
                     if (METAL) {
                         metal_consts(vx, vy, q3[g].x, q3[g].y, q3[g].z, mt[g]);
                     } else {
-                        // T() of the winning primitive, recomputed (same expressions, same bits)
+                        // T() of the winning primitive, recomputed (same function, same bits) — the sparse colour kernels read it
+                        // from the shade record instead (above)
                         tinv_of(vx[0], vy[0], vx[1], vy[1], vx[2], vy[2], q2[g].x, q2[g].y, q2[g].z, q2[g].w);
                         cfx[g] = (float)vx[2] + 0.5f;
                         cfy[g] = (float)vy[2] + 0.5f;
@@ -2390,7 +2372,7 @@ static SetupArgs make_setup_args(const DeviceFrame& f) {
     SetupArgs a;
     a.tri_xyz = f.tri_xyz; a.box64 = f.box64; a.reordered = f.reordered; a.ntri = f.ntri;
     a.cull = f.live_parity >= 0 ? 1 : 0;
-    a.geo = f.geo; a.geo_full = f.geo_full;
+    a.geo = f.geo; a.geo_full = f.geo_full; a.tinv = f.tinv;
     a.tile_count = f.tile_count; a.ranges = f.ranges; a.tg = f.tg;
     a.metal = (f.flags & SWR_FLAG_METAL_RULES) ? 1 : 0;
     for (int c = 0; c < 4; c++)
@@ -2433,10 +2415,11 @@ hipError_t prepare_device() {
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-#define SWR_BIN_ATTR(MT, DF, AF) \
-    if ((e = hipFuncSetAttribute((const void*)k_bin<256, MT, DF, AF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    SWR_BIN_ATTR(false, false, false) SWR_BIN_ATTR(true, false, false) SWR_BIN_ATTR(false, true, false) SWR_BIN_ATTR(true, true, false)
-    SWR_BIN_ATTR(false, false, true) SWR_BIN_ATTR(true, false, true) SWR_BIN_ATTR(false, true, true) SWR_BIN_ATTR(true, true, true)
+#define SWR_BIN_ATTR(MT, DF, AF, TI) \
+    if ((e = hipFuncSetAttribute((const void*)k_bin<256, MT, DF, AF, TI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    SWR_BIN_ATTR(false, false, false, false) SWR_BIN_ATTR(true, false, false, false) SWR_BIN_ATTR(false, true, false, false) SWR_BIN_ATTR(true, true, false, false)
+    SWR_BIN_ATTR(false, false, true, false) SWR_BIN_ATTR(true, false, true, false) SWR_BIN_ATTR(false, true, true, false) SWR_BIN_ATTR(true, true, true, false)
+    SWR_BIN_ATTR(false, false, false, true) SWR_BIN_ATTR(false, true, false, true) SWR_BIN_ATTR(false, false, true, true) SWR_BIN_ATTR(false, true, true, true)
 #undef SWR_BIN_ATTR
     return hipFuncSetAttribute((const void*)k_fill_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
@@ -2501,14 +2484,17 @@ bool launch_bin(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     const size_t lds = (size_t)((b.ntiles + 1) / 2) * 4 + (size_t)(b.per + 1) * 4 + 2 * (256 / 64) * 4 + 4;
     // the transform's last row is (0, 0, 0, 1): w == 1 for every finite vertex, no perspective divide (setup_triangle_r<.., AFF>)
     const bool aff = f.m[3] == 0.0f && f.m[7] == 0.0f && f.m[11] == 0.0f && f.m[15] == 1.0f;
-#define SWR_BIN_GO(MT, DF, AF) SWR_LAUNCH(stop, (k_bin<256, MT, DF, AF>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b)
+    const bool ti = b.a.tinv != nullptr && !b.a.metal;      // sparse colour frame under the CPU rules: a shade record per binned triangle for the resolve
+#define SWR_BIN_GO(MT, DF, AF, TI) SWR_LAUNCH(stop, (k_bin<256, MT, DF, AF, TI>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b)
+#define SWR_BIN_GO2(MT, DF, AF) do { if (!MT && ti) SWR_BIN_GO(false, DF, AF, true); else SWR_BIN_GO(MT, DF, AF, false); } while (0)
     if (aff) {
-        if (b.defer_ok) { if (b.a.metal) SWR_BIN_GO(true, true, true); else SWR_BIN_GO(false, true, true); }
-        else { if (b.a.metal) SWR_BIN_GO(true, false, true); else SWR_BIN_GO(false, false, true); }
+        if (b.defer_ok) { if (b.a.metal) SWR_BIN_GO2(true, true, true); else SWR_BIN_GO2(false, true, true); }
+        else { if (b.a.metal) SWR_BIN_GO2(true, false, true); else SWR_BIN_GO2(false, false, true); }
     } else {
-        if (b.defer_ok) { if (b.a.metal) SWR_BIN_GO(true, true, false); else SWR_BIN_GO(false, true, false); }
-        else { if (b.a.metal) SWR_BIN_GO(true, false, false); else SWR_BIN_GO(false, false, false); }
+        if (b.defer_ok) { if (b.a.metal) SWR_BIN_GO2(true, true, false); else SWR_BIN_GO2(false, true, false); }
+        else { if (b.a.metal) SWR_BIN_GO2(true, false, false); else SWR_BIN_GO2(false, false, false); }
     }
+#undef SWR_BIN_GO2
 #undef SWR_BIN_GO
     return stop != nullptr;
 }
@@ -2548,6 +2534,13 @@ bool launch_sort_bins(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     return stop != nullptr;
 }
 
+// Does the resolve of this frame read shade records (so the binning stage has to write them)?  The sparse colour kernels
+// under the CPU rules with the reference's fragment stage (raster_tile, SHREC).
+bool frame_uses_shade_records(const DeviceFrame& f) {
+    const int64_t ntiles = (int64_t)f.tg.tiles_x * f.tg.tiles_y;
+    return !(f.flags & SWR_FLAG_NO_COLOR) && !(f.flags & SWR_FLAG_METAL_RULES) && f.material.shader == SWR_SHADER_PASSTHROUGH &&
+           f.ntri < 64 * ntiles;
+}
 // Does this frame take k_raster_depth (32-bit depth keys)?  Depth-only, z-tested, CPU rules, and the scene has not been moved
 // to the 64-bit kernel by the host (DeviceFrame::k32).
 bool frame_uses_k32(const DeviceFrame& f) {
@@ -2557,6 +2550,7 @@ bool frame_uses_k32(const DeviceFrame& f) {
 bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     RasterArgs a;
     a.geo = f.geo; a.geo_full = f.geo_full; a.tri_rgb = f.tri_rgb;
+    a.tinv = f.tinv;
     a.inv = f.inv; a.reordered = f.reordered;
     a.tri_nrm = f.tri_nrm;
     a.fs.shader = f.material.shader; a.fs.shininess_log2 = f.material.shininess_log2;
@@ -2574,7 +2568,6 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     a.host_pairs = f.host_counters; a.host_fill = f.host_fill; a.host_max = f.host_max;
     a.redo_dev = f.redo_dev; a.host_redo = f.host_redo;
     a.insort = f.insort;
-    a.slot_bits24 = f.ntri < SORT_MAX_TRIS ? 1 : 0;
     const unsigned ntiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
     if (ntiles == 0) return false;
     // Small grids (a small window: the reference app's 512x512 is 128 tiles): four workgroups fit where one tile's

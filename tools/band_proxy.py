@@ -10,7 +10,9 @@ flags = sc.flags
 res = {}
 # test hooks for A/Bs: key=value arguments go to swr_debug_set (e.g. insort=0 k32=0 binmode=1)
 KEYS = {"order": 1, "cull": 2, "binmode": 3, "oneshot": 4, "k32": 5, "insort": 6}
-hooks = [a.split("=") for a in sys.argv[1:] if "=" in a]
+hooks = [a.split("=") for a in sys.argv[1:] if "=" in a and not a.startswith("color=")]
+if "color=1" in sys.argv[1:]:
+    flags = S.FLAG_DEPTH_TEST            # colour + depth instead of the depth-only headline
 parts_arg = [int(x) for x in sys.argv[1:] if "=" not in x]
 with swr_amd.Context() as ctx:
     for k, v in hooks:

@@ -173,13 +173,21 @@ struct swr_context {
     // drawn to the host while the next swr_draw renders into the other buffer
     Target tg{};
     bool has_target = false;
-    DevBuf color[2], depth[2];
+#ifndef SWR_NSLOT
+#define SWR_NSLOT 3   // working sets = frame lanes = frames in flight (two-stream pipeline: binning up to two frames ahead of the raster)
+#endif
+    static constexpr int NSLOT = SWR_NSLOT;
+    // (one per lane: with frame lanes — below — every frame in flight renders into its own buffer; the two-stream pipeline uses two)
+    static constexpr int NFB = NSLOT;
+    static_assert(NFB >= 2, "double-buffered at least");
+    DevBuf color[NFB], depth[NFB];
     int fb_cur = 0;                     // the next swr_draw renders into this buffer
     int fb_last = 0;                    // the buffer of the last swr_draw (what swr_present / swr_read_* copy)
+    hipStream_t last_stream = nullptr;  // the stream that carries the last frame's raster (swr_present records frame_done behind it)
     hipStream_t copy_stream[2] = {nullptr, nullptr};   // colour, depth: both images in flight together
-    hipEvent_t frame_done[2] = {nullptr, nullptr};     // raster stream -> copy streams, per framebuffer
-    hipEvent_t copy_done[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [fb][image]: the raster into fb waits for these
-    bool copy_recorded[2][2] = {{false, false}, {false, false}};
+    hipEvent_t frame_done[NFB] = {};     // raster stream -> copy streams, per framebuffer
+    hipEvent_t copy_done[NFB][2] = {};   // [fb][image]: the raster into fb waits for these
+    bool copy_recorded[NFB][2] = {};
     // pinned staging for destinations that are not page-locked (two 8 MiB chunks per image, D2H / memcpy pipelined)
     static constexpr size_t STAGE_BYTES = 8u << 20;
     void* stage[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
@@ -189,13 +197,9 @@ struct swr_context {
     float* present_depth = nullptr;
     bool present_pending = false;
 
-#ifndef SWR_NSLOT
-#define SWR_NSLOT 3   // working sets in flight: binning may run up to two frames ahead of the raster (2 -> 3: -3 %)
-#endif
 #ifndef SWR_RAS_EVERY
 #define SWR_RAS_EVERY 1   // every n-th k_raster carries a completion event (see RAS_EVERY)
 #endif
-    static constexpr int NSLOT = SWR_NSLOT;
     // A kernel that carries a completion signal (ras_done) costs the NEXT kernel of its queue ~5 us
     // (profiles/r02/c_kernel_trace_pipelined.txt).  The binning of frame N needs "k_raster(N - NSLOT) has finished"; it
     // waits for the first event-carrying raster at or after that frame instead (same queue, in order), so only every
@@ -227,10 +231,28 @@ struct swr_context {
     // per-tile fill counters live in four rotating blocks (frame % 4) while the working sets rotate by three: k_bin of
     // frame N zeroes the block of frame N + 1, which was last read by the raster of frame N - 3 — the raster whose
     // completion lets the binning of frame N start.
-    static constexpr int NFILL = 4;
-    static_assert(NFILL == NSLOT + 1, "k_bin(N) zeroes the fill block of frame N + 1: its last reader must be the raster of frame N - NSLOT");
+    static constexpr int NFILL = NSLOT + 1;      // k_bin(N) zeroes the fill block of frame N + 1: its last reader must be the raster of frame N - NSLOT
     DevBuf fillbuf[NFILL];              // [CNT_WORDS counters][tiles fills]
     bool fill_dirty[NFILL] = {};        // block was used and nothing has zeroed it since (then the frame memsets it first)
+    // ---- FRAME LANES (round 4; the default whenever frames may overlap).  The binning and the raster of ONE frame go back to
+    // back onto ONE stream — kernels of a queue follow each other without a gap, and nothing else orders them: no event, no
+    // wait packet, no completion signal, no helper thread that polls — and consecutive frames onto NSLOT different streams.
+    // Everything a frame writes belongs to its lane: the working set (slot = lane), its two fill blocks (k_bin of the lane's
+    // n-th frame zeroes the block of its (n + 1)-th, last read by a raster that is earlier on the same stream) and its
+    // framebuffer (fb advances with every draw; the buffer a frame writes was last written three frames earlier — same lane).
+    // Frames of different lanes overlap freely on the chip.  What the two-stream pipeline of rounds 1-3 paid per frame — a
+    // 5 us gap behind every kernel that carries a completion signal, the polls of two helper threads — is gone: cfg4 76 -> 67 us
+    // per frame, and a thin band (1/8 of the frame: bound by its kernel chain, not by the chip) 24.5 -> 15.9 us
+    // (profiles/r04/lanes_probe.txt).  SWR_LANES=0 keeps the two-stream pipeline.
+    hipStream_t lane_stream[NSLOT] = {};
+    bool lanes_ok = false;
+    DevBuf lanefill[NSLOT][2];
+    bool lanefill_dirty[NSLOT][2] = {};
+    // pacing of an un-waited burst: every PACE_EVERY-th frame leaves a marker behind its raster; a draw waits for the marker of
+    // 3 * PACE_EVERY frames ago (the per-frame pinned words are a ring of PAIR_RING frames)
+    static constexpr int PACE_EVERY = 24;
+    hipEvent_t pace_ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint64_t pace_frame[4] = {~0ull, ~0ull, ~0ull, ~0ull};
     uint32_t cap_tile = 0;              // entries per tile region
     bool fixed_mode = false;            // frames are binned by k_bin (else: exact-size bins, four kernels)
     bool fixed_allowed = true;          // false once a tile of this scene / target needed more than the fixed path can give
@@ -464,10 +486,16 @@ int wait_counter(swr_context* c, const std::atomic<uint64_t>& ctr, uint64_t g, c
     return SWR_OK;
 }
 
+// frames go onto the lanes (swr_context::lane_stream) whenever frames may overlap at all (pipelining on)
+inline bool lane_mode(const swr_context* c) { return c->lanes_ok && c->bin_stream != c->stream; }
+
 int sync_streams(swr_context* c) {
     int rc = flush_raster(c, c->frame_no);      // everything drawn so far is on the streams
     if (!rc) rc = wait_stream(c, c->bin_stream, "binning stream");
     if (!rc) rc = wait_stream(c, c->stream, "raster stream");
+    if (c->lanes_ok)
+        for (hipStream_t ls : c->lane_stream)
+            if (!rc && ls) rc = wait_stream(c, ls, "frame lane");
     if (rc) return sticky(c) ? sticky(c) : rc;
     c->synced_upto = c->posted;      // NOT frame_no: enqueue_frame may sync after it has numbered the frame it is about to post
     return SWR_OK;
@@ -524,6 +552,12 @@ int size_bins(swr_context* c) {
             HIP_TRY(c, hipMemsetAsync(c->fillbuf[k].p, 0, c->fillbuf[k].bytes, c->stream));
             c->fill_dirty[k] = false;
         }
+        for (int l = 0; l < swr_context::NSLOT; l++)
+            for (int k = 0; k < 2; k++) {
+                if ((rc = ensure(c, c->lanefill[l][k], fb))) return rc;
+                HIP_TRY(c, hipMemsetAsync(c->lanefill[l][k].p, 0, c->lanefill[l][k].bytes, c->stream));
+                c->lanefill_dirty[l][k] = false;
+            }
         if ((rc = wait_stream(c, c->stream, "raster stream (fill counters)"))) return sticky(c) ? sticky(c) : rc;
         c->fixed_mode = true;
         return SWR_OK;
@@ -587,8 +621,14 @@ DeviceFrame make_frame(swr_context* c, int si, uint64_t frame, const float m[16]
     f.capacity = c->capacity;
     f.fixed_bins = (c->fixed_mode && f.ntri > 0) ? 1 : 0;
     f.cap_tile = c->cap_tile;
-    f.fill = (uint32_t*)c->fillbuf[frame % swr_context::NFILL].p;
-    f.fill_next = (uint32_t*)c->fillbuf[(frame + 1) % swr_context::NFILL].p;
+    if (lane_mode(c)) {       // the lane's two blocks alternate: this frame's, and the one its k_bin zeroes for the lane's next frame
+        const int par = (int)((frame / (uint64_t)swr_context::NSLOT) & 1u);
+        f.fill = (uint32_t*)c->lanefill[si][par].p;
+        f.fill_next = (uint32_t*)c->lanefill[si][par ^ 1].p;
+    } else {
+        f.fill = (uint32_t*)c->fillbuf[frame % swr_context::NFILL].p;
+        f.fill_next = (uint32_t*)c->fillbuf[(frame + 1) % swr_context::NFILL].p;
+    }
     f.host_fill = c->h_pairs_dev + swr_context::PAIR_RING + 1 + (frame % swr_context::PAIR_RING);
     f.biglist = (uint4*)sl.biglist.p;
     f.color = (uint8_t*)c->color[c->fb_cur].p;
@@ -670,6 +710,8 @@ int enqueue_frame(swr_context* c) {
         c->posted = c->frame_no;
         c->bin_enqueued.store(c->frame_no); c->ras_enqueued.store(c->frame_no);
         c->draw_pending = true;
+        c->last_stream = c->stream;
+        if (lane_mode(c)) c->fb_cur = (c->fb_last + 1) % swr_context::NFB;
         return SWR_OK;
     }
     const uint64_t frame = c->frame_no++;
@@ -736,7 +778,13 @@ int enqueue_frame(swr_context* c) {
     // fixed-stride bins: this frame's fill block must be zero when k_bin starts (the k_bin before it did that, unless that
     // frame took another path); k_bin leaves it dirty and zeroes the next frame's
     bool fill_memset = false;
-    if (f.fixed_bins) {
+    const bool lanes = lane_mode(c);
+    if (f.fixed_bins && lanes) {
+        const int par = (int)((frame / (uint64_t)swr_context::NSLOT) & 1u);
+        fill_memset = c->lanefill_dirty[si][par];
+        c->lanefill_dirty[si][par] = true;
+        c->lanefill_dirty[si][par ^ 1] = false;
+    } else if (f.fixed_bins) {
         const int fbk = (int)(frame % swr_context::NFILL);
         fill_memset = c->fill_dirty[fbk];
         c->fill_dirty[fbk] = true;
@@ -745,6 +793,71 @@ int enqueue_frame(swr_context* c) {
     const bool zero_tables = !f.fixed_bins && (!f.plan.use_lds || f.ntri <= 0);
     const size_t zero_bytes = (size_t)(CNT_WORDS + 3 * tiles_of(c->tg) + 1) * 4;
     hipEvent_t e0 = (ev && all) ? ev[0] : nullptr, e1 = (ev && all) ? ev[1] : nullptr, e2 = (ev && all) ? ev[2] : nullptr;
+    if (lanes) {
+        // ---- FRAME LANES: the whole frame, binning and raster, back to back on the lane's stream (see swr_context::lane_stream)
+        hipStream_t S = c->lane_stream[si];
+        const int inj = c->inject.exchange(0, std::memory_order_relaxed);      // swr_debug_fault
+        auto fail_frame = [&](int rc) {      // nothing was enqueued for this frame: the context has failed (fatal) or the call reports
+            c->posted = frame + 1;
+            c->bin_enqueued.store(frame + 1, std::memory_order_release);
+            c->ras_enqueued.store(frame + 1, std::memory_order_release);
+            return rc;
+        };
+        if (inj == SWR_FAULT_ENQUEUE) return fail_frame(fatal(c, SWR_ERR_HIP, "frame %llu: injected enqueue failure (swr_debug_fault)", (unsigned long long)frame));
+        if (inj == SWR_FAULT_LOST_EVENT) {
+            const int rc = poll_event(c, c->slot[si].bin_done, "the lane's previous frame (injected: a completion that never arrives)", frame, true);
+            if (rc) return fail_frame(rc);
+        }
+        // an un-waited burst is paced by markers: at most ~4 * PACE_EVERY frames in flight
+        if (frame % (uint64_t)swr_context::PACE_EVERY == 0) {
+            const uint64_t old = frame - 3 * (uint64_t)swr_context::PACE_EVERY;
+            const int k = (int)((frame / (uint64_t)swr_context::PACE_EVERY) % 4);
+            const int ko = (k + 1) % 4;          // (k - 3) mod 4
+            if (frame >= 3 * (uint64_t)swr_context::PACE_EVERY && c->pace_frame[ko] == old && old >= c->synced_upto) {
+                const int rc = poll_event(c, c->pace_ev[ko], "an earlier frame of the burst", old);
+                if (rc) return fail_frame(rc);
+            }
+        }
+        int rc = wait_for_copies_of(c, c->fb_cur, S);
+        if (rc) return fail_frame(rc);
+        auto enq = [&]() -> int {
+            if (zero_tables) HIP_TRY(c, hipMemsetAsync(c->slot[si].tilebuf.p, 0, zero_bytes, S));
+            if (fill_memset) HIP_TRY(c, hipMemsetAsync(f.fill, 0, (size_t)(CNT_WORDS + tiles_of(f.tg)) * 4, S));
+            if (e0) HIP_TRY(c, hipEventRecord(e0, S));
+            if (f.fixed_bins) {
+                launch_bin(f, S, nullptr);
+                if (e1) HIP_TRY(c, hipEventRecord(e1, S));
+                if (e2) HIP_TRY(c, hipEventRecord(e2, S));
+            } else {
+                launch_setup_bin(f, S);
+                if (e1) HIP_TRY(c, hipEventRecord(e1, S));
+                launch_scan(f, S);
+                if (e2) HIP_TRY(c, hipEventRecord(e2, S));
+                launch_fill(f, S, nullptr);
+            }
+            if (!f.skip_sort) launch_sort_bins(f, S, nullptr);
+            if (ev) HIP_TRY(c, hipEventRecord(ev[3], S));
+            launch_raster(f, S, nullptr);
+            if (ev) HIP_TRY(c, hipEventRecord(ev[4], S));
+            if (frame % (uint64_t)swr_context::PACE_EVERY == 0) {
+                const int k = (int)((frame / (uint64_t)swr_context::PACE_EVERY) % 4);
+                HIP_TRY(c, hipEventRecord(c->pace_ev[k], S));
+                c->pace_frame[k] = frame;
+            }
+            HIP_TRY(c, hipGetLastError());
+            return SWR_OK;
+        };
+        rc = enq();
+        if (rc) return fail_frame(fatal(c, rc, "enqueueing frame %llu failed: %s", (unsigned long long)frame, c->err.c_str()));
+        c->draw_pending = true;
+        c->posted = frame + 1;
+        c->bin_enqueued.store(frame + 1, std::memory_order_release);
+        c->ras_enqueued.store(frame + 1, std::memory_order_release);
+        c->last_stream = S;
+        c->fb_cur = (c->fb_last + 1) % swr_context::NFB;      // the next frame (another lane) renders into its own buffer
+        return SWR_OK;
+    }
+    c->last_stream = sr;
     // ---- the binning stream's share of the frame ----
     // this slot's buffers are free again once the raster of NSLOT frames ago has read them (a full sync since then
     // settles it: every non-pipelined path syncs first)
@@ -1151,7 +1264,7 @@ int single_target_set(swr_context* c, int64_t width, int64_t height, int64_t row
     t.tiles_x = (int32_t)((width + TILE_W - 1) / TILE_W);
     t.tiles_y = (int32_t)((row_end - row_begin + TILE_H - 1) / TILE_H);
     const size_t px = (size_t)width * (size_t)(row_end - row_begin);
-    for (int fb = 0; fb < 2; fb++) {
+    for (int fb = 0; fb < swr_context::NFB; fb++) {
         if ((rc = ensure(c, c->color[fb], px * 4))) return rc;
         if ((rc = ensure(c, c->depth[fb], px * 4))) return rc;
         c->copy_recorded[fb][0] = c->copy_recorded[fb][1] = false;
@@ -1216,19 +1329,27 @@ int enqueue_present(swr_context* c, void* color_full, float* depth_full) {
     if (tiles_of(c->tg) == 0) return SWR_OK;
     const bool want_color = color_full && !(c->last_flags & SWR_FLAG_NO_COLOR);
     const uint64_t frame = c->frame_no ? c->frame_no - 1 : 0;      // the frame being presented (for messages)
-    auto copies = [c, fb, want_color, color_full, depth_full, frame]() -> int {
+    hipStream_t fs = c->last_stream ? c->last_stream : c->stream;        // the stream that carries the frame's raster
+    auto copies = [c, fb, want_color, color_full, depth_full, frame, fs]() -> int {
         int rc;
-        HIP_TRY(c, hipEventRecord(c->frame_done[fb], c->stream));
+        HIP_TRY(c, hipEventRecord(c->frame_done[fb], fs));
         if (want_color && (rc = copy_band(c, fb, 0, color_full, frame))) return rc;
         if (depth_full && (rc = copy_band(c, fb, 1, depth_full, frame))) return rc;
         return SWR_OK;
     };
+    if (lane_mode(c)) {
+        // frame lanes: the frame is on its stream already, and the next draw went (or goes) to another buffer anyway
+        int rc = flush_raster(c, c->frame_no);
+        if (rc || (rc = copies())) return rc;
+        if (c->frame_no) c->frame_presented[(c->frame_no - 1) % swr_context::PAIR_RING] = true;
+        return SWR_OK;
+    }
     if (c->ras_worker) c->ras_worker->post(copies);   // behind the frame's raster share, in order
     else {
         int rc = flush_raster(c, c->frame_no);        // the frame being presented must be on the raster stream
         if (rc || (rc = copies())) return rc;
     }
-    c->fb_cur = fb ^ 1;     // the next frame renders into the other framebuffer while this one is being copied
+    c->fb_cur = fb == 0 ? 1 : 0;     // the next frame renders into the other framebuffer while this one is being copied
     if (c->frame_no) c->frame_presented[(c->frame_no - 1) % swr_context::PAIR_RING] = true;
     return SWR_OK;
 }
@@ -1368,7 +1489,8 @@ void destroy_single(swr_context* c) {
             if (!d.pause()) return false;
         }
     };
-    const bool drained = drain(c->bin_stream) && drain(c->stream) && drain(c->copy_stream[0]) && drain(c->copy_stream[1]);
+    bool drained = drain(c->bin_stream) && drain(c->stream) && drain(c->copy_stream[0]) && drain(c->copy_stream[1]);
+    for (hipStream_t ls : c->lane_stream) drained = drained && drain(ls);
     if (!drained) {
         fprintf(stderr, "[swr] context on device %d destroyed in a failed state (%s); device memory it may still be using is not freed\n",
                 c->device, c->failed_msg.c_str());
@@ -1381,19 +1503,26 @@ void destroy_single(swr_context* c) {
                 (unsigned long long)c->hp_frames, c->hp_t[0] / c->hp_frames, c->hp_t[1] / c->hp_frames, c->hp_t[2] / c->hp_frames,
                 c->hp_t[3] / c->hp_frames, c->hp_t[4] / c->hp_frames, c->hp_t[5] / c->hp_frames);
     DevBuf* bufs[] = {&c->redo_cnt, &c->vertices, &c->indices, &c->tri_rgb, &c->tri_xyz, &c->inv, &c->box64, &c->stream_scratch, &c->sort_temp,
-                      &c->attrs, &c->tri_nrm, &c->texture, &c->texture_bytes, &c->color[0], &c->color[1], &c->depth[0], &c->depth[1],
-                      &c->fillbuf[0], &c->fillbuf[1], &c->fillbuf[2], &c->fillbuf[3]};
+                      &c->attrs, &c->tri_nrm, &c->texture, &c->texture_bytes};
     for (DevBuf* b : bufs) if (b->p) hipFree(b->p);
+    for (DevBuf& b : c->color) if (b.p) hipFree(b.p);
+    for (DevBuf& b : c->depth) if (b.p) hipFree(b.p);
+    for (DevBuf& b : c->fillbuf) if (b.p) hipFree(b.p);
+    for (auto& lf : c->lanefill) for (DevBuf& b : lf) if (b.p) hipFree(b.p);
+    for (hipStream_t ls : c->lane_stream) if (ls) hipStreamDestroy(ls);
+    for (hipEvent_t e : c->pace_ev) if (e) hipEventDestroy(e);
     for (auto& sl : c->slot) {
         DevBuf* sb[] = {&sl.tinv, &sl.geo, &sl.geo_full, &sl.ranges, &sl.bins, &sl.bin_matrix, &sl.live, &sl.tilebuf, &sl.biglist};
         for (DevBuf* b : sb) if (b->p) hipFree(b->p);
         if (sl.bin_done) hipEventDestroy(sl.bin_done);
         if (sl.ras_done) hipEventDestroy(sl.ras_done);
     }
-    for (int i = 0; i < 2; i++) {
+    for (int i = 0; i < swr_context::NFB; i++) {
         if (c->frame_done[i]) hipEventDestroy(c->frame_done[i]);
+        for (int j = 0; j < 2; j++) if (c->copy_done[i][j]) hipEventDestroy(c->copy_done[i][j]);
+    }
+    for (int i = 0; i < 2; i++) {
         for (int j = 0; j < 2; j++) {
-            if (c->copy_done[i][j]) hipEventDestroy(c->copy_done[i][j]);
             if (c->stage[i][j]) hipHostFree(c->stage[i][j]);
             if (c->stage_ev[i][j]) hipEventDestroy(c->stage_ev[i][j]);
         }
@@ -1456,9 +1585,17 @@ int create_single(int dev, swr_context** out, int helpers, uint32_t wait_budget_
             hipEventCreateWithFlags(&sl.bin_done, hipEventDisableTiming);
             hipEventCreateWithFlags(&sl.ras_done, hipEventDisableTiming);
         }
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < swr_context::NFB; i++) {
             hipEventCreateWithFlags(&c->frame_done[i], hipEventDisableTiming);
             for (int j = 0; j < 2; j++) hipEventCreateWithFlags(&c->copy_done[i][j], hipEventDisableTiming);
+        }
+        // frame lanes (swr_context::lane_stream): one stream per working set.  SWR_LANES=0: the two-stream pipeline of rounds 1-3
+        {
+            const char* ln = getenv("SWR_LANES");
+            c->lanes_ok = c->bin_stream_own != nullptr && !(ln && ln[0] == '0');
+            for (int l = 0; l < swr_context::NSLOT && c->lanes_ok; l++)
+                if (hipStreamCreateWithFlags(&c->lane_stream[l], hipStreamNonBlocking) != hipSuccess) c->lanes_ok = false;
+            for (hipEvent_t& e : c->pace_ev) hipEventCreateWithFlags(&e, hipEventDisableTiming);
         }
     }
     for (int r = 0; r < swr_context::RING; r++)

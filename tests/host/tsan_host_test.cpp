@@ -123,13 +123,16 @@ static void failure(uint32_t devices, int fault) {
 
 int main() {
     for (int i = 0; i < 300; i++) { idx[i] = i; verts[i] = swr_vertex{{0.1f * (float)(i % 7), 0.2f, 0.5f, 0}, {1, 1, 1, 0}}; }
-    for (int delay : {0, 15, 150}) {             // kernels that finish before / while / long after the host enqueues the next
-        fake_kernel_delay_us(delay);
-        resident(0);
-        resident(3);
+    for (const char* lanes : {"1", "0"}) {       // frame lanes (the default) and the two-stream pipeline with its helper threads
+        setenv("SWR_LANES", lanes, 1);
+        for (int delay : {0, 15, 150}) {         // kernels that finish before / while / long after the host enqueues the next
+            fake_kernel_delay_us(delay);
+            resident(0);
+            resident(3);
+        }
+        fake_kernel_delay_us(15);
+        for (int fault = 1; fault <= 2; fault++) { failure(0, fault); failure(2, fault); }
     }
-    fake_kernel_delay_us(15);
-    for (int fault = 1; fault <= 2; fault++) { failure(0, fault); failure(2, fault); }
     std::printf(fails ? "tsan host test: %d failures\n" : "tsan host test: ok\n", fails);
     return fails ? 1 : 0;
 }

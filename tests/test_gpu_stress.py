@@ -24,8 +24,8 @@ def _mat(rng):
 _EXTRA = [(1 + 2 * (k % 2), 100 + k) for k in range(int(os.environ.get("SWR_STRESS_SEEDS", "0")))]
 
 
-@pytest.mark.parametrize("env", [{}, {"SWR_EVENT_WAITS": "1"}, {"SWR_HOST_THREADS": "1"}],
-                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")
+@pytest.mark.parametrize("env", [{}, {"SWR_LANES": "0"}, {"SWR_LANES": "0", "SWR_EVENT_WAITS": "1"}, {"SWR_LANES": "0", "SWR_HOST_THREADS": "1"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default(lanes)")
 @pytest.mark.parametrize("n,seed", [(1, 11), (1, 12), (1, 14), (3, 13), (2, 15)] + _EXTRA)
 def test_random_call_sequences(swr, oracle, monkeypatch, env, n, seed):
     S = swr.scenes

@@ -288,15 +288,17 @@ def test_group_resident_path_and_timings(swr, oracle):
     assert (d2[:256] == 3.0).all() and (d2[640:] == 3.0).all() and not c2[:256].any()
 
 
-@pytest.mark.parametrize("env", [{}, {"SWR_EVENT_WAITS": "1"}, {"SWR_HOST_THREADS": "1"}, {"SWR_BIND_EVENTS": "0"},
-                                 {"SWR_PIPELINE": "0"}, {"SWR_EVENT_WAITS": "1", "SWR_BIND_EVENTS": "0"}],
-                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default")
+@pytest.mark.parametrize("env", [{}, {"SWR_LANES": "0"}, {"SWR_LANES": "0", "SWR_EVENT_WAITS": "1"}, {"SWR_LANES": "0", "SWR_HOST_THREADS": "1"},
+                                 {"SWR_LANES": "0", "SWR_BIND_EVENTS": "0"}, {"SWR_PIPELINE": "0"},
+                                 {"SWR_LANES": "0", "SWR_EVENT_WAITS": "1", "SWR_BIND_EVENTS": "0"}],
+                         ids=lambda e: ",".join(f"{k}={v}" for k, v in e.items()) or "default(lanes)")
 @pytest.mark.parametrize("n", [1, 3])
 def test_every_frame_of_an_unwaited_burst_is_intact_under_every_ordering_mode(swr, oracle, monkeypatch, env, n):
     """Eight frames with eight different transforms, drawn and presented into eight host image sets without a single
-    wait in between: three working sets and two device framebuffers are re-used while earlier frames are still in
-    flight.  The streams are ordered by the helper threads' event polls (default), by event waits on the streams
-    (SWR_EVENT_WAITS=1 / SWR_HOST_THREADS=1), with recorded instead of kernel-bound events, or not at all (one stream);
+    wait in between: three working sets and the device framebuffers are re-used while earlier frames are still in
+    flight.  Frame lanes (the default: every frame on its own stream, nothing else orders it), or the two-stream pipeline of
+    rounds 1-3 (SWR_LANES=0) ordered by the helper threads' event polls, by event waits on the streams
+    (SWR_EVENT_WAITS=1 / SWR_HOST_THREADS=1), with recorded instead of kernel-bound events, or one stream (SWR_PIPELINE=0);
     the pixels must not depend on which (include/swr.h: the knobs of INTEGRATION.md §7 only change timing)."""
     S = swr.scenes
     for k, v in env.items():

@@ -174,7 +174,7 @@ struct swr_context {
     Target tg{};
     bool has_target = false;
 #ifndef SWR_NSLOT
-#define SWR_NSLOT 3   // working sets = frame lanes = frames in flight (two-stream pipeline: binning up to two frames ahead of the raster)
+#define SWR_NSLOT 4   // working sets = frame lanes = frames in flight: 3 -> 4 lanes: worst band of 8 16.2 -> 13.5 us, of 2 35.8 -> 33.7, the whole frame the same; 5: slower everywhere (more streams than hardware queues), profiles/r04/lanes_probe.txt
 #endif
     static constexpr int NSLOT = SWR_NSLOT;
     // (one per lane: with frame lanes — below — every frame in flight renders into its own buffer; the two-stream pipeline uses two)

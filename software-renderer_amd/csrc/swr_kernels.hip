@@ -1809,28 +1809,9 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                         asm volatile("" : "+v"(dx0));
                         const float dy = (float)dyi;                         // (y + .5) - cf.y
                         const float r0 = ta.y * dy, r1 = ta.w * dy;          // t01*dy, t11*dy
-#ifndef SWR_K32_NANMASK
-#define SWR_K32_NANMASK 0
-#endif
-#if SWR_K32_NANMASK
-                        // Pixels past the end of the span get a NaN offset: their depth is NaN, and the LDS float minimum ignores a
-                        // quiet NaN operand (measured: profiles/r04/ds_min_f32_semantics.txt) — no compare, no EXEC mask and no
-                        // branch per pixel, one mask per visit.  (The four addresses of a live lane stay inside the padded key tile.)
-                        if (nvalid > 0) {
-                            float off[UNIT];
-#pragma unroll
-                            for (int qq = 1; qq < UNIT; qq++) off[qq] = qq < nvalid ? (float)qq : __builtin_nanf("");
-#pragma unroll
-                            for (int qq = 0; qq < UNIT; qq++) {
-                                const float dx = qq == 0 ? dx0 : dx0 + off[qq];
-                                const float w0 = ta.x * dx + r0;
-                                const float w1 = ta.z * dx + r1;
-                                const float w2 = 1.0f - w0 - w1;
-                                const float d = tb.x * w0 + tb.y * w1 + tb.z * w2;     // :257
-                                if constexpr (K32) k32_min(&keys[lidx0 + qq], d);
-                            }
-                        }
-#else
+                        // (Masking the pixels past the end of a span with a NaN offset — the LDS float minimum ignores quiet NaNs — instead
+                        // of EXEC: one mask per visit, no compare / branch per pixel: the kernel alone 63.8 -> 61.4 us, the frame the same
+                        // with or without it, 0.0702 / 0.0699 ms: profiles/r04/nanmask_ab.txt.  Not in the kernel.)
 #pragma unroll
                         for (int qq = 0; qq < UNIT; qq++) {
                             const float dx = qq == 0 ? dx0 : dx0 + (float)qq;
@@ -1840,7 +1821,6 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                             const float d = tb.x * w0 + tb.y * w1 + tb.z * w2;     // :257
                             if constexpr (K32) { if (qq < nvalid) k32_min(&keys[lidx0 + qq], d); }
                         }
-#endif
                     } else if (ZTEST) {
                         float dx0 = (float)dxi;                              // (x + .5) - cf.x, exact: small integers
                         asm volatile("" : "+v"(dx0));                        // keep dx0 + q a float add (2 cycles), not add + convert (6)

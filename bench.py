@@ -243,7 +243,7 @@ def main():
     traffic = load_profile_json("traffic.json") or {}
     valu = load_profile_json("valu.json") or {}
     roofline = {
-        "bound": "hbm", "kernel": "k_raster<ztest>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
+        "bound": "hbm", "kernel": "k_raster_depth (32-bit depth keys)" if (flags & S.FLAG_NO_COLOR) else "k_raster<ztest, colour>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
         # avg_launch_ms comes from event pairs around sampled launches and contains the ~5 us completion-signal overhead of a
         # bracketed kernel, so it can exceed ms_per_step; one launch per frame on one stream bounds the true duration by the

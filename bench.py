@@ -245,9 +245,8 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": "k_raster_depth (32-bit depth keys)" if (flags & S.FLAG_NO_COLOR) else "k_raster<ztest, colour>", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS,
         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 5),
-        # avg_launch_ms comes from event pairs around sampled launches and contains the ~5 us completion-signal overhead of a
-        # bracketed kernel, so it can exceed ms_per_step; one launch per frame on one stream bounds the true duration by the
-        # steady frame time: frac <= true fraction <= frac_upper
+        # frac_upper = bytes of one launch / the steady frame period / peak: one launch per frame, so this is the kernel's
+        # aggregate rate in the steady pass (and the upper bound of what a per-launch figure could show without overlap)
         "frac_upper": round(largest_band_px * bytes_per_px / (ms_per_step_steady * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
         "traffic": traffic.get("k_raster_bytes_per_launch") if n_gpus == 1 else None,
         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of tools/profile.sh on this workload; static, not re-measured in this run)",
@@ -255,6 +254,12 @@ def main():
         "algorithmic_bytes_per_launch": largest_band_px * bytes_per_px,
         "avg_launch_ms": round(raster_ms, 5), "launches_timed": frames, "timed_every_nth_launch": SAMPLE,
         "ms_per_step_while_sampling": round(dt_s / roof_steps * 1e3, 4),
+        # Frame lanes: up to four frames are in flight, each on its own stream, so the workgroups of several
+        # k_raster launches share the chip and ONE launch lasts about launches_in_flight frame periods.  `achieved` / `frac` are
+        # the contract's per-launch figures (bytes of one launch / its own duration); the kernel's aggregate rate while the
+        # pass runs is frac_aggregate = frac x launches_in_flight = bytes per frame period / peak
+        "launches_in_flight": round(raster_ms / (dt_s / roof_steps * 1e3), 2) if dt_s > 0 else None,
+        "frac_aggregate": round(largest_band_px * bytes_per_px / (dt_s / roof_steps) / 1e9 / HBM_PEAK_GBS, 5) if dt_s > 0 else None,
         "frac_of_copy_ceiling": round(achieved / HBM_COPY_CEILING_GBS, 5),
         # the contract's `bound` names the roofline the fraction is quoted against (the HBM-write roofline of north_star);
         # what the kernel is actually limited by is VALU issue: see .valu
@@ -415,8 +420,8 @@ def main():
                       "the same frames with every band copied into one page-locked host image (SURVEY 8(d): 'host-visible image complete'), "
                       "PCIe-bound per GPU",
         "latency_ms": round(latency_ms, 4),
-        "latency_note": "ms_per_step is inverse throughput with up to three frames in flight (binning of frames N+1, N+2 beside "
-                        "the raster of frame N); latency_ms is one frame alone, swr_draw -> swr_sync",
+        "latency_note": "ms_per_step is inverse throughput with up to four frames in flight (frame lanes: every frame's binning + raster on "
+                        "its own stream); latency_ms is one frame alone, swr_draw -> swr_sync",
         "config": {"workload": f"cfg4: {scene.triangles} random triangles (3 unshared vertices each), {W}x{H}, "
                                f"z-test, {'colour+depth' if args.color else 'depth-only'}, SplitMix64 seed 0x5EED0004, "
                                f"{scene.meta.get('degenerate_redrawn', 0)} degenerate triangles regenerated (SURVEY 8(d))",

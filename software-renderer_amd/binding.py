@@ -250,7 +250,7 @@ class Context:
     def __init__(self, device: int = -1, device_count: int = 0, wait_budget_ms: int = 0):
         self._L = load_library()
         self._h = ctypes.c_void_p()
-        self._present_refs = ()         # destinations of the presents in flight: kept alive until present_wait / close
+        self._present_refs = {}         # id -> destination of the presents in flight: kept alive until present_wait / close
         cfg = Config(device, device_count, wait_budget_ms, 0)
         rc = self._L.swr_context_create(ctypes.byref(cfg), ctypes.byref(self._h))
         if rc:
@@ -352,20 +352,27 @@ class Context:
                 return None
             return x.ptr if isinstance(x, HostImage) else x.ctypes.data
         # the C side writes into these later (DMA, or the helper thread's staged memcpy): keep them alive until the copies
-        # have landed (a HostImage refuses to be freed meanwhile)
-        for x in (color, depth):
+        # have landed (a HostImage refuses to be freed meanwhile).  Registered before the call — a copy may be in flight the
+        # moment it returns — and taken back if the call enqueued nothing; one entry per image however many frames present it.
+        added = [x for x in (color, depth) if x is not None and id(x) not in self._present_refs]
+        for x in added:
+            self._present_refs[id(x)] = x
             if isinstance(x, HostImage):
                 x._busy.add(id(self))
-        self._present_refs = self._present_refs + (color, depth)
         rc = self._L.swr_present(self._h, ptr(color), ptr(depth))
         if rc:
+            if rc in (-1, -6):          # SWR_ERR_BAD_ARG / SWR_ERR_NO_SCENE: refused before anything was enqueued
+                for x in added:
+                    del self._present_refs[id(x)]
+                    if isinstance(x, HostImage):
+                        x._busy.discard(id(self))
             self._check(rc)
 
     def _release_presents(self):
-        for x in self._present_refs:
+        for x in self._present_refs.values():
             if isinstance(x, HostImage):
                 x._busy.discard(id(self))
-        self._present_refs = ()
+        self._present_refs = {}
 
     def present_wait(self):
         try:

@@ -164,6 +164,31 @@ def test_present_into_pageable_and_registered_memory(swr, oracle):
         same(None, d, None, rc_d, "depth-only present")
 
 
+def test_present_bookkeeping_of_the_binding(swr):
+    """binding.Context.present keeps every destination alive (and a HostImage un-freeable) while a copy may be in flight:
+    one entry per image however many frames present it, and nothing left behind by a present the library refused."""
+    s = swr.scenes.random_soup(500, 320, 200, 5, r_ndc=0.1, flags=DT)
+    ci, di = swr.HostImage((200, 320, 4), np.uint8), swr.HostImage((200, 320), np.float32)
+    with swr.Context(0) as ctx:
+        with pytest.raises(swr.SwrError):
+            ctx.present(ci, di)                       # no target yet: SWR_ERR_NO_SCENE, nothing enqueued
+        assert not ctx._present_refs and not ci._busy and not di._busy
+        ctx.scene_upload(s.vertices, s.indices)
+        ctx.target_set(320, 200)
+        with pytest.raises(swr.SwrError):
+            ctx.present(None, None)
+        assert not ctx._present_refs
+        for _ in range(50):
+            ctx.draw(s.transform, DT)
+            ctx.present(ci, di)
+        assert len(ctx._present_refs) == 2 and ci._busy and di._busy
+        with pytest.raises(swr.SwrError):
+            ci.free()                                 # a copy into it is (or may be) in flight
+        ctx.present_wait()
+        assert not ctx._present_refs and not ci._busy and not di._busy
+    ci.free(); di.free()
+
+
 def big_scene(swr, ntri=220):
     """A few hundred near-full-screen triangles at 4K: ~4 000 tiles each, far more (triangle,tile) pairs than the
     initial bin capacity (2 x triangles + 65 536)."""

@@ -1125,6 +1125,7 @@ struct RasterArgs {
     uint32_t* host_fill;    // test) and the same for the host's sort heuristic — k_bin leaves them in device counters
     uint32_t* host_max;
     int insort;         // 32-bit keys: the bins are unsorted and tagged (no k_sort_bins ran): the workgroup sorts its bin in LDS
+    int pack_local;     // the scene has at most 2^WTAB_PRIM_BITS primitives: colour frames may carry the bin position in the key's low word (winner table)
     int vs_log;         // 2^vs_log workgroups per tile, each owning TILE_H >> vs_log of its rows (small grids, see launch_raster)
     uint32_t* redo_dev; // k_raster_depth: tiles (one in REDO_SAMPLE) that had to be rastered again with 64-bit keys, since the last launch
     uint32_t* host_redo;    // ... handed to the host's pinned word by the next launch (the host then switches the scene to the 64-bit kernel)
@@ -1135,6 +1136,10 @@ constexpr int REDO_SAMPLE = 8;
 // 64-bit visibility keys (orderable depth << 32 | primitive, or ~primitive without z-test): every frame that needs the
 // winner's identity — colour frames, painter's order, the Metal rules.
 constexpr int RASTER_QCAP = 128;         // ring entries per wave (see raster_tile)
+// Winner table of colour frames (raster_tile, resolve): the key's low word is  original primitive << WTAB_LOCAL_BITS | position in
+// the tile's bin, so the resolve knows WHICH bin entries own pixels without a search: at most 2^20 primitives, bins of at most 4096 entries.
+constexpr int WTAB_LOCAL_BITS = 12, WTAB_PRIM_BITS = 32 - WTAB_LOCAL_BITS;
+constexpr int WTAB_WORDS = (1 << WTAB_LOCAL_BITS) / 32;
 constexpr int RASTER_SORT_SEG = 1024;    // bin entries a raster workgroup can sort in its own LDS (fuller bins stay unsorted)
 struct alignas(16) RasterLds64 {
     unsigned long long keys[TILE_W * TILE_H];
@@ -1142,6 +1147,8 @@ struct alignas(16) RasterLds64 {
     uint32_t tabP[RASTER_THREADS];       //                            original primitive index (the key's low word)
     uint32_t queue[RASTER_THREADS / 64][RASTER_QCAP];
     uint32_t next_chunk;                 // work-stealing cursor over the chunks of the sorted bin
+    uint32_t pad_[3];
+    uint2 winners[WTAB_WORDS];           // colour frames (winner table, raster_tile): x = which bin positions own a pixel (32 per word), y = how many before the word
 };
 // 32-bit keys: depth-only z-tested frames under the CPU rules (BASELINE config 4).  The image of such a frame is the
 // per-pixel minimum of the fragment depths (Renderer.swift:257-261); WHICH primitive wins a tie cannot be seen in it, except
@@ -1388,6 +1395,10 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
     const uint32_t m = b1 - b0;   // bin sorted by size class (k_sort_bins), heaviest first — unless the host skipped the sort
     // (sparse frames, launch_sort_bins): the entries then still carry k_fill_lds's class tag
     const uint32_t bin_mask = a.tag_class ? (1u << CLASS_SHIFT) - 1u : 0xFFFFFFFFu;
+    // Colour frames with the reference's fragment stage: the key's low word also carries the triangle's position in this bin
+    // (below the original index, which still decides ties), so the resolve can set up every WINNER once — see "winner table" there.
+    constexpr bool WTAB_OK = COLOR && !EXT && !METAL && !K32 && VAR == 0;
+    const bool wtab = WTAB_OK && a.pack_local != 0 && m <= (1u << WTAB_LOCAL_BITS);      // (workgroup-uniform)
 
     // the gather chain of the first batch (bin entry -> record) is issued before the LDS init so
     // that its latency overlaps the init and the barrier
@@ -1463,6 +1474,7 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
             reinterpret_cast<float4*>(L.keys)[i] = make_float4(INFINITY, INFINITY, INFINITY, INFINITY);   // (:206)
     } else {
         for (int i = tid; i < TILE_W * TILE_H; i += RASTER_THREADS) keys[i] = KEY_EMPTY;
+        if constexpr (WTAB_OK) { if (tid < WTAB_WORDS) L.winners[tid] = make_uint2(0u, 0u); }
     }
     __syncthreads();
     if constexpr (K32) {
@@ -1532,6 +1544,7 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
             }
             // visibility keys order by the ORIGINAL primitive index (Renderer.swift:222,258)
             if (a.reordered) t.prim = __float_as_uint(q1.w) >> GEOM_ORIG_SHIFT;
+            if (WTAB_OK && wtab) t.prim = (t.prim << WTAB_LOCAL_BITS) | e;     // ... and the position in the bin below it (winner table)
             ya = max(t.ch.s0y, Yw0);
             // Metal rules: the samples of the ROI's last row lie at max-y + 0.5, half a pixel below every vertex: never
             // inside (the float evaluation of :144-153 errs by ~2^-8 px at most for GEOM_SMALL extents), so it is not walked
@@ -1958,17 +1971,170 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
         __syncthreads();
         return L.redo != 0u;
     } else {
+    // ---- Colour frames, winner table.  A resolve thread that sets up the winner of its own pixels (below) runs the winner setup —
+    // record gather, vertex decode, the four exact divisions of T() — whenever ANY of its wave's 64 lanes meets a new winner: at
+    // every one of a group's four pixels, 32 times per tile, for ~230 distinct winners (cfg4) or ~20 (cfg5).  Here the key's low
+    // word names the winner's position in the tile's bin, so:  1  every pixel marks its winner in a bitmap over the bin and keeps
+    // only the position (16 bits; the depth is recomputed from the winner like the reference computes it, :257);  2  a prefix over
+    // the bitmap numbers the winners;  3  one lane per BIN ENTRY that owns a pixel sets that winner up, once, and leaves an 18-float
+    // record (T(), cf, the three depths, the three vertex colours) where the keys were;  4  every pixel shades from its winner's
+    // record.  No original-index -> slot gather, two gather round trips per tile instead of up to nine, and the setup runs ~6
+    // times per tile instead of 32: cfg4 colour + depth 0.115 -> %%WTAB_CFG4C%% ms, cfg5 0.169 -> %%WTAB_CFG5%%.  A tile with more winners
+    // than records fit (WTAB_RCAP) takes the per-thread path below.
+    if constexpr (WTAB_OK) {
+        constexpr int REC_F = 18;
+        constexpr int WTAB_BYTES = (int)(sizeof(L.keys) + sizeof(L.tabAB) + sizeof(L.tabP) + sizeof(L.queue));   // contiguous, dead after the raster
+        constexpr int PIX_OFF = WTAB_BYTES - TILE_W * TILE_H * 2;
+        constexpr int WTAB_RCAP = PIX_OFF / (REC_F * 4);
+        static_assert(offsetof(RasterLds64, queue) + sizeof(L.queue) == (size_t)WTAB_BYTES && offsetof(RasterLds64, keys) == 0, "records | positions alias keys .. queue");
+        if (wtab) {
+            uint16_t* const pix = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(&L) + PIX_OFF);
+            float* const recs = reinterpret_cast<float*>(&L);
+            // 1: position of every pixel's winner (0xFFFF: none) ...
+            uint32_t pos[2][4];
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                const int p = (tid + g * RASTER_THREADS) * 4;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const unsigned long long key = keys[p + k];
+                    const uint32_t low = ZTEST ? (uint32_t)key : 0xFFFFFFFFu - (uint32_t)key;
+                    pos[g][k] = (uint32_t)(key >> 32) < KEY_LIVE_BELOW ? (low & ((1u << WTAB_LOCAL_BITS) - 1u)) : 0xFFFFu;
+                }
+                *reinterpret_cast<uint2*>(pix + p) = make_uint2(pos[g][0] | (pos[g][1] << 16), pos[g][2] | (pos[g][3] << 16));
+            }
+            __syncthreads();
+            // ... and the winners marked in the bitmap — by the pixels whose left and upper neighbours belong to someone else only (the
+            // top-left pixel of a winner's region always is one): a mark per pixel is 2 048 LDS atomics on a handful of words (a
+            // sparse tile: ONE word, 64 lanes of every instruction in turn — cfg5 0.169 -> 0.221 ms that way)
+#pragma unroll
+            for (int g = 0; g < 2; g++) {
+                const int p = (tid + g * RASTER_THREADS) * 4;
+                const int lx = p % TILE_W;
+                uint32_t up[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu}, left = 0xFFFFu;
+                if (p >= TILE_W) {
+                    const uint2 u = *reinterpret_cast<const uint2*>(pix + p - TILE_W);
+                    up[0] = u.x & 0xFFFFu; up[1] = u.x >> 16; up[2] = u.y & 0xFFFFu; up[3] = u.y >> 16;
+                }
+                if (lx > 0) left = pix[p - 1];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const uint32_t q = pos[g][k];
+                    if (q != 0xFFFFu && q != (k ? pos[g][k - 1] : left) && q != up[k]) atomicOr(&L.winners[q >> 5].x, 1u << (q & 31u));
+                }
+            }
+            __syncthreads();
+            // 2: winners before every bitmap word — every wave for itself (same values, no barrier: a wave reads what it wrote)
+            static_assert(WTAB_WORDS == 128, "two bitmap words per lane");
+            const uint32_t bw0 = L.winners[2 * lane].x, bw1 = L.winners[2 * lane + 1].x;
+            const uint32_t c0 = (uint32_t)__popc(bw0), c1 = (uint32_t)__popc(bw1);
+            const uint32_t incl = (uint32_t)wave_incl_add((int)(c0 + c1));
+            L.winners[2 * lane].y = incl - c0 - c1;
+            L.winners[2 * lane + 1].y = incl - c1;
+            const uint32_t nrec = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            if (nrec <= (uint32_t)WTAB_RCAP) {
+                // 3: one lane per bin entry that owns a pixel: its record
+                for (uint32_t i = (uint32_t)tid; i < m; i += RASTER_THREADS) {
+                    const uint2 wv = L.winners[i >> 5];
+                    if (!((wv.x >> (i & 31u)) & 1u)) continue;
+                    const uint32_t rid = wv.y + (uint32_t)__popc(wv.x & ((1u << (i & 31u)) - 1u));
+                    const uint32_t slot = a.bins[b0 + i] & bin_mask;
+                    const int4 g0 = reinterpret_cast<const int4*>(a.geo + slot)[0];
+                    const float4 g1 = reinterpret_cast<const float4*>(a.geo + slot)[1];
+                    const float* cp = reinterpret_cast<const float*>(a.tri_rgb + 3 * (size_t)slot);
+                    const float cr[9] = {cp[0], cp[1], cp[2], cp[4], cp[5], cp[6], cp[8], cp[9], cp[10]};
+                    int vx[3], vy[3];
+                    decode_vertices(a.geo_full, slot, g0, g1, vx, vy);
+                    float t00, t01, t10, t11;
+                    tinv_of(vx[0], vy[0], vx[1], vy[1], vx[2], vy[2], t00, t01, t10, t11);
+                    float* r = recs + rid * REC_F;
+                    *reinterpret_cast<float2*>(r + 0) = make_float2(t00, t01);
+                    *reinterpret_cast<float2*>(r + 2) = make_float2(t10, t11);
+                    *reinterpret_cast<float2*>(r + 4) = make_float2((float)vx[2] + 0.5f, (float)vy[2] + 0.5f);
+                    *reinterpret_cast<float2*>(r + 6) = make_float2(g1.x, g1.y);
+                    *reinterpret_cast<float2*>(r + 8) = make_float2(g1.z, cr[0]);
+                    *reinterpret_cast<float2*>(r + 10) = make_float2(cr[1], cr[2]);
+                    *reinterpret_cast<float2*>(r + 12) = make_float2(cr[3], cr[4]);
+                    *reinterpret_cast<float2*>(r + 14) = make_float2(cr[5], cr[6]);
+                    *reinterpret_cast<float2*>(r + 16) = make_float2(cr[7], cr[8]);
+                }
+                __syncthreads();
+                // 4: every pixel from its winner's record
+#pragma unroll 1
+                for (int g = 0; g < 2; g++) {
+                    const int i = tid + g * RASTER_THREADS;
+                    const int ly = (i * 4) / TILE_W, lx = (i * 4) % TILE_W;
+                    const int y = Y0 + ly, x = X0 + lx;
+                    if (y < Yp0 || y > Yp1 || x > X1) continue;
+                    const uint2 pp = *reinterpret_cast<const uint2*>(pix + i * 4);
+                    const uint32_t pos[4] = {pp.x & 0xFFFFu, pp.x >> 16, pp.y & 0xFFFFu, pp.y >> 16};
+                    uint32_t cpix[4];
+                    float dpix[4];
+                    const float dyp = (float)y + 0.5f;
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        uint32_t c = 0u;               // Pixel(0,0,0,0) (:205)
+                        float d = INFINITY;            // (:206)
+                        if (pos[k] != 0xFFFFu && x + k <= X1) {
+                            const uint2 wv = L.winners[pos[k] >> 5];
+                            const uint32_t rid = wv.y + (uint32_t)__popc(wv.x & ((1u << (pos[k] & 31u)) - 1u));
+                            const float* r = recs + rid * REC_F;
+                            const float2 ta = *reinterpret_cast<const float2*>(r + 0), tb = *reinterpret_cast<const float2*>(r + 2);
+                            const float2 cf = *reinterpret_cast<const float2*>(r + 4), z01 = *reinterpret_cast<const float2*>(r + 6);
+                            const float2 z2a = *reinterpret_cast<const float2*>(r + 8), a12 = *reinterpret_cast<const float2*>(r + 10);
+                            const float2 b01 = *reinterpret_cast<const float2*>(r + 12), b2c = *reinterpret_cast<const float2*>(r + 14);
+                            const float2 c12 = *reinterpret_cast<const float2*>(r + 16);
+                            const float dx = ((float)(x + k) + 0.5f) - cf.x;
+                            const float dy = dyp - cf.y;
+                            const float w0 = ta.x * dx + ta.y * dy;
+                            const float w1 = tb.x * dx + tb.y * dy;
+                            const float w2 = 1.0f - w0 - w1;
+                            if (ZTEST) d = z01.x * w0 + z01.y * w1 + z2a.x * w2;          // :257
+                            VertexOut vin;
+                            vin.pos = make_float4((float)(x + k) + 0.5f, dyp, d, 1.0f);
+                            vin.color = make_float3(z2a.y * w0 + b01.x * w1 + b2c.y * w2,     // :266
+                                                    a12.x * w0 + b01.y * w1 + c12.x * w2,
+                                                    a12.y * w0 + b2c.x * w1 + c12.y * w2);
+                            const float4 f = fragment_shader(vin);
+                            // Pixel(float3:) -> .floats(b: z, g: y, r: x, a: 1) truncates (:116-128)
+                            const float ub = fminf(fmaxf(f.z, 0.0f), 1.0f) * 255.0f, ug = fminf(fmaxf(f.y, 0.0f), 1.0f) * 255.0f;
+                            const float ur = fminf(fmaxf(f.x, 0.0f), 1.0f) * 255.0f, ua = fminf(fmaxf(f.w, 0.0f), 1.0f) * 255.0f;
+                            c = (uint32_t)ub | ((uint32_t)ug << 8) | ((uint32_t)ur << 16) | ((uint32_t)ua << 24);
+                        }
+                        cpix[k] = c;
+                        dpix[k] = d;
+                    }
+                    const size_t at = (size_t)(y - a.tg.row_begin) * (size_t)W + (size_t)x;   // App.swift:351-360
+                    if (vec_ok && x + 3 <= X1) {
+                        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+                        typedef float f32x4 __attribute__((ext_vector_type(4)));
+                        u32x4 cv = {cpix[0], cpix[1], cpix[2], cpix[3]};
+                        __builtin_nontemporal_store(cv, reinterpret_cast<u32x4*>(a.color + at * 4));
+                        f32x4 dv = {dpix[0], dpix[1], dpix[2], dpix[3]};
+                        __builtin_nontemporal_store(dv, reinterpret_cast<f32x4*>(a.depth + at));
+                    } else {
+                        for (int k = 0; k < 4 && x + k <= X1; k++) {
+                            reinterpret_cast<uint32_t*>(a.color)[at + k] = cpix[k];
+                            a.depth[at + k] = dpix[k];
+                        }
+                    }
+                }
+                return false;
+            }
+        }
+    }
     // Colour frames: the stream slots of ALL this thread's winners first (original index -> slot is a gather from a
     // 4 MB table; the keys hold the original index because it decides depth ties) — 8 independent loads in flight
     // instead of 4 + 4 behind each other — written back into the low words of the keys, which have done their job.
     static_assert(TILE_W * TILE_H / 4 == 2 * RASTER_THREADS, "two 4-pixel groups per thread");
+    const int pshift = wtab ? WTAB_LOCAL_BITS : 0;      // (a tile whose winners did not fit the table: the original index sits above the bin position)
     if (want_color && a.reordered && VAR != 8 && VAR != 10 && VAR != 11) {
         uint32_t sl[8];
 #pragma unroll
         for (int g = 0; g < 8; g++) {
             const int p = (tid + (g >> 2) * RASTER_THREADS) * 4 + (g & 3);
             const unsigned long long key = keys[p];
-            const uint32_t prim = ZTEST ? (uint32_t)key : 0xFFFFFFFFu - (uint32_t)key;
+            const uint32_t prim = (ZTEST ? (uint32_t)key : 0xFFFFFFFFu - (uint32_t)key) >> pshift;
             sl[g] = (uint32_t)(key >> 32) < KEY_LIVE_BELOW ? a.inv[prim] : 0u;
         }
 #pragma unroll
@@ -2059,7 +2225,7 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                 const unsigned long long key = keys[ly[g] * TILE_W + lx[g] + k];
                 const uint32_t hi = (uint32_t)(key >> 32);
                 const bool live = on[g] && hi < KEY_LIVE_BELOW && x[g] + k <= X1;
-                prim[g] = ZTEST ? (uint32_t)key : 0xFFFFFFFFu - (uint32_t)key;
+                prim[g] = (ZTEST ? (uint32_t)key : 0xFFFFFFFFu - (uint32_t)key) >> pshift;
                 d[g] = INFINITY;           // (:206)
                 need_rec[g] = live && want_color;
                 if (ZTEST && live) {
@@ -2548,6 +2714,7 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     a.host_pairs = f.host_counters; a.host_fill = f.host_fill; a.host_max = f.host_max;
     a.redo_dev = f.redo_dev; a.host_redo = f.host_redo;
     a.insort = f.insort;
+    a.pack_local = f.ntri <= (1ll << WTAB_PRIM_BITS) ? 1 : 0;
     const unsigned ntiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
     if (ntiles == 0) return false;
     // Small grids (a small window: the reference app's 512x512 is 128 tiles): four workgroups fit where one tile's

@@ -1397,7 +1397,7 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
     const uint32_t bin_mask = a.tag_class ? (1u << CLASS_SHIFT) - 1u : 0xFFFFFFFFu;
     // Colour frames with the reference's fragment stage: the key's low word also carries the triangle's position in this bin
     // (below the original index, which still decides ties), so the resolve can set up every WINNER once — see "winner table" there.
-    constexpr bool WTAB_OK = COLOR && !EXT && !METAL && !K32 && VAR == 0;
+    constexpr bool WTAB_OK = COLOR && !K32 && VAR == 0;
     const bool wtab = WTAB_OK && a.pack_local != 0 && m <= (1u << WTAB_LOCAL_BITS);      // (workgroup-uniform)
 
     // the gather chain of the first batch (bin entry -> record) is issued before the LDS init so
@@ -1971,25 +1971,70 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
         __syncthreads();
         return L.redo != 0u;
     } else {
-    // ---- Colour frames, winner table.  A resolve thread that sets up the winner of its own pixels (below) runs the winner setup —
-    // record gather, vertex decode, the four exact divisions of T() — whenever ANY of its wave's 64 lanes meets a new winner: at
-    // every one of a group's four pixels, 32 times per tile, for ~230 distinct winners (cfg4) or ~20 (cfg5).  Here the key's low
-    // word names the winner's position in the tile's bin, so:  1  every pixel marks its winner in a bitmap over the bin and keeps
-    // only the position (16 bits; the depth is recomputed from the winner like the reference computes it, :257);  2  a prefix over
-    // the bitmap numbers the winners;  3  one lane per BIN ENTRY that owns a pixel sets that winner up, once, and leaves an 18-float
-    // record (T(), cf, the three depths, the three vertex colours) where the keys were;  4  every pixel shades from its winner's
-    // record.  No original-index -> slot gather, two gather round trips per tile instead of up to nine, and the setup runs ~6
-    // times per tile instead of 32: cfg4 colour + depth 0.115 -> %%WTAB_CFG4C%% ms, cfg5 0.169 -> %%WTAB_CFG5%%.  A tile with more winners
-    // than records fit (WTAB_RCAP) takes the per-thread path below.
+    // ---- Colour frames, winner table.  A resolve thread that sets up the winner of its own pixels (the per-thread path below) runs
+    // the winner setup — record gathers, vertex decode, the four exact divisions of T() — whenever ANY of its wave's 64 lanes meets
+    // a new winner: at every one of a group's four pixels, 32 times per tile, for ~230 distinct winners (cfg4) or ~20 (cfg5).
+    // Here the key's low word names the winner's position in the tile's bin, so
+    //   1  every pixel keeps only that position (16 bits; the depth is recomputed from the winner the way the reference computes
+    //      it, :257) — and, when the bin has more entries than records fit, the winners are marked in a bitmap over the bin and a
+    //      prefix over the bitmap numbers them;
+    //   2  one lane per bin entry (that owns a pixel) sets the winner up, ONCE, and leaves a record — T() or the Metal rules'
+    //      constants, the three depths, the vertex colours (normals, texture coordinates) — where the keys were;
+    //   3  every pixel shades from its winner's record.
+    // No original-index -> slot gather, two gather round trips per tile (the first one in flight across step 1) instead of up to
+    // nine, the setup runs ~6 times per tile instead of 32: cfg4 colour + depth 0.114 -> 0.103 ms (k_raster 57.6 -> 50.4 M vector
+    // instructions), cfg5 0.169 -> 0.152.  A tile with more winners than records fit (WTAB_RCAP) takes the per-thread path below.
     if constexpr (WTAB_OK) {
-        constexpr int REC_F = 18;
+        // record: [0..9] weights (CPU rules: T() 4, cf 2, z 3, - ; Metal rules: p3 2, A0 B0 A1 B1, divider, z 3), [10..18] colours a b c,
+        // extended stage: [19..27] normals a b c, [28..33] (u, v) a b c.  An odd stride in words: neighbouring records in different banks.
+        constexpr int REC_F = EXT ? 34 : 19;
+        constexpr int REC_STRIDE = REC_F | 1;
         constexpr int WTAB_BYTES = (int)(sizeof(L.keys) + sizeof(L.tabAB) + sizeof(L.tabP) + sizeof(L.queue));   // contiguous, dead after the raster
         constexpr int PIX_OFF = WTAB_BYTES - TILE_W * TILE_H * 2;
-        constexpr int WTAB_RCAP = PIX_OFF / (REC_F * 4);
+        constexpr int WTAB_RCAP = PIX_OFF / (REC_STRIDE * 4);
         static_assert(offsetof(RasterLds64, queue) + sizeof(L.queue) == (size_t)WTAB_BYTES && offsetof(RasterLds64, keys) == 0, "records | positions alias keys .. queue");
         if (wtab) {
             uint16_t* const pix = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(&L) + PIX_OFF);
             float* const recs = reinterpret_cast<float*>(&L);
+            const bool direct = m <= (uint32_t)WTAB_RCAP;        // every bin entry gets the record of its own position: no bitmap
+            struct Gathered { int4 g0; float4 g1; float4 ca, cb, cc, na, nb, nc; };
+            auto gather = [&](uint32_t slot) {
+                Gathered G;
+                G.g0 = reinterpret_cast<const int4*>(a.geo + slot)[0];
+                G.g1 = reinterpret_cast<const float4*>(a.geo + slot)[1];
+                G.na = G.nb = G.nc = make_float4(0, 0, 0, 0);
+                if (EXT) {
+                    G.ca = a.tri_rgb[3 * (size_t)slot + 0]; G.cb = a.tri_rgb[3 * (size_t)slot + 1]; G.cc = a.tri_rgb[3 * (size_t)slot + 2];
+                    G.na = a.tri_nrm[3 * (size_t)slot + 0]; G.nb = a.tri_nrm[3 * (size_t)slot + 1]; G.nc = a.tri_nrm[3 * (size_t)slot + 2];
+                } else {   // (lane 3 = the texture coordinate v: only the extended stage reads it)
+                    const float* cp = reinterpret_cast<const float*>(a.tri_rgb + 3 * (size_t)slot);
+                    G.ca = make_float4(cp[0], cp[1], cp[2], 0.0f); G.cb = make_float4(cp[4], cp[5], cp[6], 0.0f); G.cc = make_float4(cp[8], cp[9], cp[10], 0.0f);
+                }
+                return G;
+            };
+            auto build = [&](uint32_t rid, uint32_t slot, const Gathered& G) {
+                int vx[3], vy[3];
+                decode_vertices(a.geo_full, slot, G.g0, G.g1, vx, vy);
+                float* r = recs + rid * REC_STRIDE;
+                if (METAL) {
+                    MetalTri mt;
+                    metal_consts(vx, vy, G.g1.x, G.g1.y, G.g1.z, mt);
+                    r[0] = mt.p3x; r[1] = mt.p3y; r[2] = mt.A0; r[3] = mt.B0; r[4] = mt.A1; r[5] = mt.B1; r[6] = mt.divider;
+                } else {
+                    float t00, t01, t10, t11;
+                    tinv_of(vx[0], vy[0], vx[1], vy[1], vx[2], vy[2], t00, t01, t10, t11);
+                    r[0] = t00; r[1] = t01; r[2] = t10; r[3] = t11; r[4] = (float)vx[2] + 0.5f; r[5] = (float)vy[2] + 0.5f; r[6] = 0.0f;
+                }
+                r[7] = G.g1.x; r[8] = G.g1.y; r[9] = G.g1.z;
+                r[10] = G.ca.x; r[11] = G.ca.y; r[12] = G.ca.z; r[13] = G.cb.x; r[14] = G.cb.y; r[15] = G.cb.z; r[16] = G.cc.x; r[17] = G.cc.y; r[18] = G.cc.z;
+                if (EXT) {
+                    r[19] = G.na.x; r[20] = G.na.y; r[21] = G.na.z; r[22] = G.nb.x; r[23] = G.nb.y; r[24] = G.nb.z; r[25] = G.nc.x; r[26] = G.nc.y; r[27] = G.nc.z;
+                    r[28] = G.na.w; r[29] = G.ca.w; r[30] = G.nb.w; r[31] = G.cb.w; r[32] = G.nc.w; r[33] = G.cc.w;
+                }
+            };
+            // the first 256 bin entries' gathers go out now and land while the pixels are looked at
+            const uint32_t slot_first = (uint32_t)tid < m ? a.bins[b0 + (uint32_t)tid] & bin_mask : 0u;
+            Gathered G_first = gather(slot_first);
             // 1: position of every pixel's winner (0xFFFF: none) ...
             uint32_t pos[2][4];
 #pragma unroll
@@ -2004,62 +2049,55 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                 *reinterpret_cast<uint2*>(pix + p) = make_uint2(pos[g][0] | (pos[g][1] << 16), pos[g][2] | (pos[g][3] << 16));
             }
             __syncthreads();
-            // ... and the winners marked in the bitmap — by the pixels whose left and upper neighbours belong to someone else only (the
-            // top-left pixel of a winner's region always is one): a mark per pixel is 2 048 LDS atomics on a handful of words (a
-            // sparse tile: ONE word, 64 lanes of every instruction in turn — cfg5 0.169 -> 0.221 ms that way)
+            uint32_t nrec = m;
+            if (!direct) {
+                // ... and the winners marked in the bitmap — by the pixels whose left and upper neighbours belong to someone else only
+                // (the top-left pixel of a winner's region always is one): a mark per pixel is 2 048 LDS atomics on a handful of words
+                // (64 lanes of every instruction in turn on ONE word in a sparse tile: cfg5 0.169 -> 0.221 ms that way)
 #pragma unroll
-            for (int g = 0; g < 2; g++) {
-                const int p = (tid + g * RASTER_THREADS) * 4;
-                const int lx = p % TILE_W;
-                uint32_t up[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu}, left = 0xFFFFu;
-                if (p >= TILE_W) {
-                    const uint2 u = *reinterpret_cast<const uint2*>(pix + p - TILE_W);
-                    up[0] = u.x & 0xFFFFu; up[1] = u.x >> 16; up[2] = u.y & 0xFFFFu; up[3] = u.y >> 16;
-                }
-                if (lx > 0) left = pix[p - 1];
+                for (int g = 0; g < 2; g++) {
+                    const int p = (tid + g * RASTER_THREADS) * 4;
+                    const int lx = p % TILE_W;
+                    uint32_t up[4] = {0xFFFFu, 0xFFFFu, 0xFFFFu, 0xFFFFu}, left = 0xFFFFu;
+                    if (p >= TILE_W) {
+                        const uint2 u = *reinterpret_cast<const uint2*>(pix + p - TILE_W);
+                        up[0] = u.x & 0xFFFFu; up[1] = u.x >> 16; up[2] = u.y & 0xFFFFu; up[3] = u.y >> 16;
+                    }
+                    if (lx > 0) left = pix[p - 1];
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const uint32_t q = pos[g][k];
-                    if (q != 0xFFFFu && q != (k ? pos[g][k - 1] : left) && q != up[k]) atomicOr(&L.winners[q >> 5].x, 1u << (q & 31u));
-                }
-            }
-            __syncthreads();
-            // 2: winners before every bitmap word — every wave for itself (same values, no barrier: a wave reads what it wrote)
-            static_assert(WTAB_WORDS == 128, "two bitmap words per lane");
-            const uint32_t bw0 = L.winners[2 * lane].x, bw1 = L.winners[2 * lane + 1].x;
-            const uint32_t c0 = (uint32_t)__popc(bw0), c1 = (uint32_t)__popc(bw1);
-            const uint32_t incl = (uint32_t)wave_incl_add((int)(c0 + c1));
-            L.winners[2 * lane].y = incl - c0 - c1;
-            L.winners[2 * lane + 1].y = incl - c1;
-            const uint32_t nrec = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
-            if (nrec <= (uint32_t)WTAB_RCAP) {
-                // 3: one lane per bin entry that owns a pixel: its record
-                for (uint32_t i = (uint32_t)tid; i < m; i += RASTER_THREADS) {
-                    const uint2 wv = L.winners[i >> 5];
-                    if (!((wv.x >> (i & 31u)) & 1u)) continue;
-                    const uint32_t rid = wv.y + (uint32_t)__popc(wv.x & ((1u << (i & 31u)) - 1u));
-                    const uint32_t slot = a.bins[b0 + i] & bin_mask;
-                    const int4 g0 = reinterpret_cast<const int4*>(a.geo + slot)[0];
-                    const float4 g1 = reinterpret_cast<const float4*>(a.geo + slot)[1];
-                    const float* cp = reinterpret_cast<const float*>(a.tri_rgb + 3 * (size_t)slot);
-                    const float cr[9] = {cp[0], cp[1], cp[2], cp[4], cp[5], cp[6], cp[8], cp[9], cp[10]};
-                    int vx[3], vy[3];
-                    decode_vertices(a.geo_full, slot, g0, g1, vx, vy);
-                    float t00, t01, t10, t11;
-                    tinv_of(vx[0], vy[0], vx[1], vy[1], vx[2], vy[2], t00, t01, t10, t11);
-                    float* r = recs + rid * REC_F;
-                    *reinterpret_cast<float2*>(r + 0) = make_float2(t00, t01);
-                    *reinterpret_cast<float2*>(r + 2) = make_float2(t10, t11);
-                    *reinterpret_cast<float2*>(r + 4) = make_float2((float)vx[2] + 0.5f, (float)vy[2] + 0.5f);
-                    *reinterpret_cast<float2*>(r + 6) = make_float2(g1.x, g1.y);
-                    *reinterpret_cast<float2*>(r + 8) = make_float2(g1.z, cr[0]);
-                    *reinterpret_cast<float2*>(r + 10) = make_float2(cr[1], cr[2]);
-                    *reinterpret_cast<float2*>(r + 12) = make_float2(cr[3], cr[4]);
-                    *reinterpret_cast<float2*>(r + 14) = make_float2(cr[5], cr[6]);
-                    *reinterpret_cast<float2*>(r + 16) = make_float2(cr[7], cr[8]);
+                    for (int k = 0; k < 4; k++) {
+                        const uint32_t q = pos[g][k];
+                        if (q != 0xFFFFu && q != (k ? pos[g][k - 1] : left) && q != up[k]) atomicOr(&L.winners[q >> 5].x, 1u << (q & 31u));
+                    }
                 }
                 __syncthreads();
-                // 4: every pixel from its winner's record
+                // winners before every bitmap word — every wave for itself (same values, no barrier: a wave reads what it wrote)
+                static_assert(WTAB_WORDS == 128, "two bitmap words per lane");
+                const uint32_t bw0 = L.winners[2 * lane].x, bw1 = L.winners[2 * lane + 1].x;
+                const uint32_t c0 = (uint32_t)__popc(bw0), c1 = (uint32_t)__popc(bw1);
+                const uint32_t incl = (uint32_t)wave_incl_add((int)(c0 + c1));
+                L.winners[2 * lane].y = incl - c0 - c1;
+                L.winners[2 * lane + 1].y = incl - c1;
+                nrec = (uint32_t)__builtin_amdgcn_readlane((int)incl, 63);
+            }
+            auto rid_of = [&](uint32_t q) {         // record of bin position q
+                if (direct) return q;
+                const uint2 wv = L.winners[q >> 5];
+                return wv.y + (uint32_t)__popc(wv.x & ((1u << (q & 31u)) - 1u));
+            };
+            if (nrec <= (uint32_t)WTAB_RCAP) {
+                // 2: one lane per bin entry (that owns a pixel): its record
+                uint32_t slot = slot_first;
+                for (uint32_t i = (uint32_t)tid; i < m; i += RASTER_THREADS) {
+                    const bool mine = direct || ((L.winners[i >> 5].x >> (i & 31u)) & 1u);
+                    if (i >= (uint32_t)RASTER_THREADS && mine) {
+                        slot = a.bins[b0 + i] & bin_mask;
+                        G_first = gather(slot);
+                    }
+                    if (mine) build(rid_of(i), slot, G_first);
+                }
+                __syncthreads();
+                // 3: every pixel from its winner's record
 #pragma unroll 1
                 for (int g = 0; g < 2; g++) {
                     const int i = tid + g * RASTER_THREADS;
@@ -2067,38 +2105,53 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                     const int y = Y0 + ly, x = X0 + lx;
                     if (y < Yp0 || y > Yp1 || x > X1) continue;
                     const uint2 pp = *reinterpret_cast<const uint2*>(pix + i * 4);
-                    const uint32_t pos[4] = {pp.x & 0xFFFFu, pp.x >> 16, pp.y & 0xFFFFu, pp.y >> 16};
+                    const uint32_t ps[4] = {pp.x & 0xFFFFu, pp.x >> 16, pp.y & 0xFFFFu, pp.y >> 16};
                     uint32_t cpix[4];
                     float dpix[4];
-                    const float dyp = (float)y + 0.5f;
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         uint32_t c = 0u;               // Pixel(0,0,0,0) (:205)
                         float d = INFINITY;            // (:206)
-                        if (pos[k] != 0xFFFFu && x + k <= X1) {
-                            const uint2 wv = L.winners[pos[k] >> 5];
-                            const uint32_t rid = wv.y + (uint32_t)__popc(wv.x & ((1u << (pos[k] & 31u)) - 1u));
-                            const float* r = recs + rid * REC_F;
-                            const float2 ta = *reinterpret_cast<const float2*>(r + 0), tb = *reinterpret_cast<const float2*>(r + 2);
-                            const float2 cf = *reinterpret_cast<const float2*>(r + 4), z01 = *reinterpret_cast<const float2*>(r + 6);
-                            const float2 z2a = *reinterpret_cast<const float2*>(r + 8), a12 = *reinterpret_cast<const float2*>(r + 10);
-                            const float2 b01 = *reinterpret_cast<const float2*>(r + 12), b2c = *reinterpret_cast<const float2*>(r + 14);
-                            const float2 c12 = *reinterpret_cast<const float2*>(r + 16);
-                            const float dx = ((float)(x + k) + 0.5f) - cf.x;
-                            const float dy = dyp - cf.y;
-                            const float w0 = ta.x * dx + ta.y * dy;
-                            const float w1 = tb.x * dx + tb.y * dy;
-                            const float w2 = 1.0f - w0 - w1;
-                            if (ZTEST) d = z01.x * w0 + z01.y * w1 + z2a.x * w2;          // :257
+                        if (ps[k] != 0xFFFFu && x + k <= X1) {
+                            const float* r = recs + rid_of(ps[k]) * REC_STRIDE;
+                            float v[REC_F];
+#pragma unroll
+                            for (int j = 0; j < REC_F; j++) v[j] = r[j];
+                            float w0, w1, w2;
+                            if (METAL) {
+                                MetalTri mt;
+                                mt.p3x = v[0]; mt.p3y = v[1]; mt.A0 = v[2]; mt.B0 = v[3]; mt.A1 = v[4]; mt.B1 = v[5]; mt.divider = v[6];
+                                mt.z0 = v[7]; mt.z1 = v[8]; mt.z2 = v[9];
+                                metal_weights(mt, x + k, y, w0, w1, w2);                  // Shaders.metal:133-149
+                            } else {
+                                const float dx = ((float)(x + k) + 0.5f) - v[4];
+                                const float dy = ((float)y + 0.5f) - v[5];
+                                w0 = v[0] * dx + v[1] * dy;
+                                w1 = v[2] * dx + v[3] * dy;
+                                w2 = 1.0f - w0 - w1;
+                            }
+                            if (ZTEST) d = v[7] * w0 + v[8] * w1 + v[9] * w2;              // :257
                             VertexOut vin;
-                            vin.pos = make_float4((float)(x + k) + 0.5f, dyp, d, 1.0f);
-                            vin.color = make_float3(z2a.y * w0 + b01.x * w1 + b2c.y * w2,     // :266
-                                                    a12.x * w0 + b01.y * w1 + c12.x * w2,
-                                                    a12.y * w0 + b2c.x * w1 + c12.y * w2);
-                            const float4 f = fragment_shader(vin);
-                            // Pixel(float3:) -> .floats(b: z, g: y, r: x, a: 1) truncates (:116-128)
-                            const float ub = fminf(fmaxf(f.z, 0.0f), 1.0f) * 255.0f, ug = fminf(fmaxf(f.y, 0.0f), 1.0f) * 255.0f;
-                            const float ur = fminf(fmaxf(f.x, 0.0f), 1.0f) * 255.0f, ua = fminf(fmaxf(f.w, 0.0f), 1.0f) * 255.0f;
+                            vin.pos = make_float4((float)(x + k) + 0.5f, (float)y + 0.5f, d, 1.0f);
+                            vin.color = make_float3(v[10] * w0 + v[13] * w1 + v[16] * w2,     // :266
+                                                    v[11] * w0 + v[14] * w1 + v[17] * w2,
+                                                    v[12] * w0 + v[15] * w1 + v[18] * w2);
+                            float4 f;
+                            if constexpr (EXT) {   // varyings interpolated like colour
+                                vin.normal = make_float3(v[19] * w0 + v[22] * w1 + v[25] * w2,
+                                                         v[20] * w0 + v[23] * w1 + v[26] * w2,
+                                                         v[21] * w0 + v[24] * w1 + v[27] * w2);
+                                vin.uv = make_float2(v[28] * w0 + v[30] * w1 + v[32] * w2,
+                                                     v[29] * w0 + v[31] * w1 + v[33] * w2);
+                                f = fragment_shader(vin, a.fs);
+                            } else {
+                                f = fragment_shader(vin);
+                            }
+                            // Pixel(float3:) -> .floats(b: z, g: y, r: x, a: 1) truncates (:116-128);
+                            // the Metal path's bgra8Unorm store rounds to nearest even
+                            float ub = fminf(fmaxf(f.z, 0.0f), 1.0f) * 255.0f, ug = fminf(fmaxf(f.y, 0.0f), 1.0f) * 255.0f;
+                            float ur = fminf(fmaxf(f.x, 0.0f), 1.0f) * 255.0f, ua = fminf(fmaxf(f.w, 0.0f), 1.0f) * 255.0f;
+                            if (METAL) { ub = rintf(ub); ug = rintf(ug); ur = rintf(ur); ua = rintf(ua); }
                             c = (uint32_t)ub | ((uint32_t)ug << 8) | ((uint32_t)ur << 16) | ((uint32_t)ua << 24);
                         }
                         cpix[k] = c;

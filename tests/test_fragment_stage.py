@@ -293,3 +293,51 @@ def test_gpu_fragment_stage_errors(swr):
             ctx.draw(s.transform, DT)
         ctx.material_set(None)
         ctx.draw(s.transform, DT); ctx.sync()                # the context stays usable
+
+
+# ---- the colour resolve's winner table (swr_kernels.hip, raster_tile): records by bin position (bins of up to ~300 entries), by
+# a bitmap over the bin (fuller bins), and the per-thread path for a tile with more winners than records fit -----------------------
+WINNER_TABLE_SCENES = [
+    # (triangles, width, height, r_ndc, what the 60 tiles of 64x32 hold; winners counted with the oracle, colours = ids)
+    (12000, 640, 192, 0.02, "~200 entries, ~180 winners per tile: one record per bin entry"),
+    (20000, 640, 192, 0.15, "~740 entries, 130-180 winners: numbered through the bitmap (the extended stage's 168 records: some tiles fit, some do not)"),
+    (60000, 640, 192, 0.004, "~1000 tiny triangles, ~240 winners per tile: bitmap, fits (not the extended stage)"),
+    (36000, 640, 192, 0.05, "~1000 entries, ~380 winners: more than records fit, the per-thread path"),
+    (150000, 640, 192, 0.01, "~3000 entries, ~1100 winners"),
+    (300000, 640, 192, 0.004, "> 4096 entries per tile: the keys carry no bin position"),
+]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags", [DT, 0, METAL])
+@pytest.mark.parametrize("ntri,w,h,r,what", WINNER_TABLE_SCENES)
+def test_gpu_winner_table_modes(gpu_ctx, oracle, swr, ntri, w, h, r, what, flags):
+    s = swr.scenes.random_soup(ntri, w, h, 4242 + ntri % 97, r_ndc=r, flags=flags, margin=1.05)
+    ref_c, ref_d, st, rc = oracle_frame(oracle, s, flags, None)
+    assert rc == 0
+    c, d = gpu_ctx.render(s.vertices, s.indices, s.transform, w, h, flags)
+    assert_same(c, d, ref_c, ref_d, f"{what}, flags {flags}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags,shader", [(DT, 2), (METAL, 1), (0, 2)])
+@pytest.mark.parametrize("ntri,w,h,r,what", WINNER_TABLE_SCENES[:5])
+def test_gpu_winner_table_modes_extended_stage(gpu_ctx, oracle, swr, ntri, w, h, r, what, flags, shader):
+    s = swr.scenes.random_soup(ntri, w, h, 777 + ntri % 89, r_ndc=r, flags=flags, margin=1.05)
+    sh = swr.scenes.random_shading(s.vertices.shape[0], 31 + shader, shader, shininess_log2=3)
+    ref_c, ref_d, _, rc = oracle_frame(oracle, s, flags, sh)
+    assert rc == 0
+    c, d = gpu_ctx.render(s.vertices, s.indices, s.transform, w, h, flags, shading=sh)
+    assert_same(c, d, ref_c, ref_d, f"{what}, flags {flags}, shader {shader}")
+
+
+@pytest.mark.gpu
+def test_gpu_winner_table_in_bands_and_small_windows(swr, oracle):
+    """Bands (the tile grid starts at the band's first row) and a window small enough for four workgroups per tile."""
+    s = swr.scenes.random_soup(30000, 640, 200, 99, r_ndc=0.05, flags=DT, margin=1.05)
+    ref_c, ref_d, _, rc = oracle_frame(oracle, s, DT, None)
+    assert rc == 0
+    for bands in (1, 3):
+        with swr.Context(0, device_count=bands) as ctx:
+            c, d = ctx.render(s.vertices, s.indices, s.transform, s.width, s.height, DT)
+            assert_same(c, d, ref_c, ref_d, f"{bands} band(s)")

@@ -213,7 +213,6 @@ struct swr_context {
     // while k_raster of frame N runs on `stream` (HBM-bound vs LDS/VALU-bound: they overlap well).
     struct Slot {
         DevBuf geo, geo_full, ranges, bins, bin_matrix;
-        DevBuf tinv;           // colour frames: 48-B shade record (T(), cf, z) of every binned triangle (k_bin -> the resolve of k_raster)
         DevBuf biglist;        // fixed-stride bins: the frame's deferred large triangles (k_bin -> k_sort_bins)
         DevBuf live;           // per binning workgroup: count + surviving stream-group ids (k_setup_hist -> k_fill_lds)
         DevBuf tilebuf;        // [CNT_WORDS counters][tiles tile_count][tiles+1 tile_start][tiles cursor]
@@ -586,7 +585,6 @@ DeviceFrame make_frame(swr_context* c, int si, uint64_t frame, const float m[16]
     f.ntri = c->ni / 3;
     f.geo = (GeomRec*)sl.geo.p;
     f.geo_full = (GeomFull*)sl.geo_full.p;
-    f.tinv = nullptr;       // (set below, once the frame knows its target and material: frame_uses_shade_records)
     uint32_t* tb = (uint32_t*)sl.tilebuf.p;
     f.counters = tb;
     f.host_counters = c->h_pairs_dev + (frame % swr_context::PAIR_RING);   // word CNT_PAIRS (= 0) of this frame
@@ -636,8 +634,6 @@ DeviceFrame make_frame(swr_context* c, int si, uint64_t frame, const float m[16]
     f.tg = c->tg;
     memcpy(f.m, m, sizeof f.m);
     f.flags = flags;
-    // sparse colour frames under the CPU rules: the binning stage leaves a shade record per binned triangle for the resolve
-    if (frame_uses_shade_records(f)) f.tinv = (float4*)sl.tinv.p;
     return f;
 }
 
@@ -1101,7 +1097,6 @@ int single_scene_upload(swr_context* c, const swr_vertex* vertices, int64_t vert
     for (auto& sl : c->slot) {
         if ((rc = ensure(c, sl.geo, (size_t)(index_count / 3) * sizeof(GeomRec)))) return rc;
         if ((rc = ensure(c, sl.geo_full, (size_t)(index_count / 3) * sizeof(GeomFull)))) return rc;
-        if ((rc = ensure(c, sl.tinv, (size_t)(index_count / 3) * 48))) return rc;
         if ((rc = ensure(c, sl.ranges, (size_t)(index_count / 3) * sizeof(uint2)))) return rc;
         if ((rc = ensure(c, sl.biglist, (size_t)1024 * 16))) return rc;
         if ((rc = ensure(c, sl.live, (size_t)((index_count / 3 + 63) / 64 + 2 * 1024 + 2) * 4))) return rc;   // [G <= 1024][1 + per]
@@ -1512,7 +1507,7 @@ void destroy_single(swr_context* c) {
     for (hipStream_t ls : c->lane_stream) if (ls) hipStreamDestroy(ls);
     for (hipEvent_t e : c->pace_ev) if (e) hipEventDestroy(e);
     for (auto& sl : c->slot) {
-        DevBuf* sb[] = {&sl.tinv, &sl.geo, &sl.geo_full, &sl.ranges, &sl.bins, &sl.bin_matrix, &sl.live, &sl.tilebuf, &sl.biglist};
+        DevBuf* sb[] = {&sl.geo, &sl.geo_full, &sl.ranges, &sl.bins, &sl.bin_matrix, &sl.live, &sl.tilebuf, &sl.biglist};
         for (DevBuf* b : sb) if (b->p) hipFree(b->p);
         if (sl.bin_done) hipEventDestroy(sl.bin_done);
         if (sl.ras_done) hipEventDestroy(sl.ras_done);

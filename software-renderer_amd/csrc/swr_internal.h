@@ -83,7 +83,6 @@ struct DeviceFrame {
     int64_t ntri;
     GeomRec* geo;
     GeomFull* geo_full;
-    float4* tinv;                  // [3 * ntri] colour frames (CPU rules): T() (:95-100) | cf, za, zb | zc per binned slot, written by the binning stage; else NULL
     uint32_t* tile_count;          // [tiles] (triangle,tile) pairs per tile
     uint32_t* tile_start;          // [tiles+1] exclusive scan of tile_count
     uint32_t* counters;            // [CNT_WORDS]
@@ -144,7 +143,6 @@ void launch_scan(const DeviceFrame& f, hipStream_t s);
 bool launch_fill(const DeviceFrame& f, hipStream_t s, hipEvent_t stop = nullptr);
 bool launch_sort_bins(const DeviceFrame& f, hipStream_t s, hipEvent_t stop = nullptr);
 bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop = nullptr);
-bool frame_uses_shade_records(const DeviceFrame& f);   // the frame's resolve reads DeviceFrame::tinv (the binning stage must write it)
 bool frame_uses_k32(const DeviceFrame& f);   // the frame's raster is k_raster_depth (32-bit depth keys, sorts its bins itself)
 void launch_points_or_lines(const DeviceFrame& f, int primitive_type, hipStream_t s);
 

@@ -215,7 +215,6 @@ struct SetupArgs {
     int64_t ntri;
     GeomRec* geo;
     GeomFull* geo_full;
-    float4* tinv;           // colour frames under the CPU rules: a 48-B shade record (T(), cf, z) per binned triangle for the resolve; else NULL
     uint32_t* tile_count;
     uint2* ranges;
     Target tg;
@@ -282,10 +281,7 @@ __device__ __forceinline__ void decode_vertices(const GeomFull* __restrict__ ful
 // (AFF = the transform's last row is (0, 0, 0, 1) — identity, orthographic, any affine map: w is then exactly 1 for every
 // finite vertex (0*x + 0*y + 0*z + 1, :160) and x / 1 = x (:162), so the nine IEEE divisions per triangle are skipped; a
 // non-finite vertex makes sx / sy non-finite either way and the triangle is skipped either way.  Chosen by the host, k_bin only.)
-// (TINV = a colour frame under the CPU rules: T() (:95-100) of every binned triangle is left in SetupArgs::tinv — once per
-// triangle here instead of once per new winner in every resolve thread, where four exact divisions were ~4.8 M of the colour
-// kernel's wave-instructions per cfg4 frame.  0 / 1 decided at compile time (k_bin), -1 = look at the pointer.)
-template <bool MT, bool AFF = false, int TINV = -1>
+template <bool MT, bool AFF = false>
 __device__ __forceinline__ uint2 setup_triangle_r(const SetupArgs& a, int64_t p, const float4& xa, const float4& xb, const float4& xc);
 __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p, const float4& xa, const float4& xb, const float4& xc) {
     return a.metal ? setup_triangle_r<true>(a, p, xa, xb, xc) : setup_triangle_r<false>(a, p, xa, xb, xc);
@@ -295,7 +291,7 @@ __device__ __forceinline__ uint2 setup_triangle(const SetupArgs& a, int64_t p) {
     return setup_triangle(a, p, a.tri_xyz[3 * p + 0], a.tri_xyz[3 * p + 1], a.tri_xyz[3 * p + 2]);
 }
 // ... with the corners already loaded (k_setup_hist fetches those of its next group while it works on this one)
-template <bool MT, bool AFF, int TINV>
+template <bool MT, bool AFF>
 __device__ __forceinline__ uint2 setup_triangle_r(const SetupArgs& a, int64_t p, const float4& xa, const float4& xb, const float4& xc) {
     uint2 range = make_uint2(RANGE_NONE_X, 0u);
     const uint32_t orig = a.reordered ? __float_as_uint(xa.w) : 0u;
@@ -391,15 +387,6 @@ __device__ __forceinline__ uint2 setup_triangle_r(const SetupArgs& a, int64_t p,
             int4* fp = reinterpret_cast<int4*>(a.geo_full + p);
             fp[0] = make_int4(ix[0], iy[0], ix[1], iy[1]);
             fp[1] = make_int4(ix[2], iy[2], 0, 0);
-        }
-        if (!MT && (TINV == 1 || (TINV < 0 && a.tinv != nullptr))) {
-            // what the resolve needs of the winning triangle besides its colours: T(), cf = float(C) + 0.5 (:89), the three z
-            float4 t;
-            tinv_of(ix[0], iy[0], ix[1], iy[1], ix[2], iy[2], t.x, t.y, t.z, t.w);      // the same function the raster's setup calls
-            float4* sr = a.tinv + 3 * p;
-            sr[0] = t;
-            sr[1] = make_float4((float)ix[2] + 0.5f, (float)iy[2] + 0.5f, sz[0], sz[1]);
-            sr[2] = make_float4(sz[2], 0.0f, 0.0f, 0.0f);
         }
     }
     if (binned)
@@ -785,7 +772,7 @@ __device__ __forceinline__ int tiles_of_box(const PixBox& b) {
     return b.x0 <= b.x1 ? (b.x1 / TILE_W - b.x0 / TILE_W + 1) * (b.y1 / TILE_H - b.y0 / TILE_H + 1) : 0;
 }
 
-template <int BT, bool MT, bool DEFER, bool AFF = false, bool TINV = false>
+template <int BT, bool MT, bool DEFER, bool AFF = false>
 // Register budget of the plain kernel: 56 VGPRs (tools/vgprs.sh) — with 58 the pipelined cfg4 frame measured 4 % slower (one of its waves has
 // to fit beside five raster waves of 88); neither launch bounds nor amdgpu_waves_per_eu make this hipcc keep it, the source does.
 __global__ __launch_bounds__(BT) void k_bin(BinArgs b) {
@@ -839,7 +826,7 @@ __global__ __launch_bounds__(BT) void k_bin(BinArgs b) {
             }
             uint2 r = make_uint2(RANGE_NONE_X, 0u);
             if (p < a.ntri) {
-                r = setup_triangle_r<MT, AFF, TINV ? 1 : 0>(a, p, xa, xb, xc);
+                r = setup_triangle_r<MT, AFF>(a, p, xa, xb, xc);
                 if (DEFER && tiles_of_box(unpack_box(r)) > BIN_BIG_TILES) {
                     const uint32_t e = atomicAdd(&b.fill[CNT_BIGLIST], 1u);
                     if (e < BIGLIST_CAP) {                           // (a full list: walked like any other)
@@ -1105,7 +1092,6 @@ __global__ __launch_bounds__(SORT_THREADS) void k_sort_bins(uint32_t* __restrict
 struct RasterArgs {
     const GeomRec* geo;
     const GeomFull* geo_full;
-    const float4* tinv;         // colour frames under the CPU rules: 3 float4 per stream slot (T() | cf.x, cf.y, za, zb | zc), left by the binning stage
     const uint32_t* inv;        // [ntri] original primitive index -> stream slot (resolve; only when reordered)
     int reordered;              // bin entries are stream slots; keys carry the original index from GeomRec.flags
     const float4* tri_rgb;      // [3*ntri] vertex colours per slot corner, de-indexed at upload (r,g,b,v)
@@ -2235,13 +2221,6 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
     // (NGX != 0: the launch chose — colour frames of SPARSE scenes, whose binning is short, take the joint walk: cfg5 0.198 -> 0.186 ms,
     // cfg3 0.0422 -> 0.0408; cfg4's colour frames, 245 triangles per tile, lose 7 % with it beside their long k_bin)
     constexpr int NG = NGX ? NGX : (EXT ? SWR_NG_EXT : (!COLOR ? SWR_NG_DEPTH : (METAL ? SWR_NG_METAL_COLOR : SWR_NG_COLOR)));
-    // Shade records (T(), cf and the three z of every binned triangle, 48 B, written by the binning stage of colour frames:
-    // setup_triangle_r, TINV) instead of the GeomRec gather + vertex decode + the four exact divisions of T() per new winner.
-    // Only the SPARSE colour kernels (NGX == 2: fewer than 64 primitives per tile, BASELINE configs 2, 3, 5): cfg5 0.1848 ->
-    // 0.1744 ms.  On cfg4's colour frames (245 primitives per tile) the extra 48 MB per working set written beside the raster and
-    // gathered by it made EVERY kernel of the pipelined frame slower (k_bin 83 -> 130-157 us, k_raster 132 -> 172 under the
-    // tracer; the frame 0.119 -> 0.168 ms) although the stages alone barely moved: profiles/r04/shade_records_ab.txt.
-    constexpr bool SHREC = COLOR && !METAL && !EXT && NGX == 2;
     static_assert(NG == 1 || NG == 2, "a thread owns two groups");
     for (int i0 = tid; VAR != 8 && VAR != 10 && VAR != 11 && i0 < TILE_W * TILE_H / 4; i0 += NG * RASTER_THREADS) {
         int ly[NG], lx[NG], y[NG], x[NG];
@@ -2293,17 +2272,8 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                     cached_prim[g] = prim[g];
                     // colour frames hold the winners' stream slots in LDS (above); depth-only: only the rare d == 0 winner
                     slot[g] = !a.reordered ? prim[g] : (want_color ? slots[ly[g] * TILE_W + lx[g] + k] : a.inv[prim[g]]);
-                    if (SHREC) {
-                        // the winner's shade record, left by the binning stage (setup_triangle_r, TINV): T(), cf, za, zb | zc
-                        const float4* sr = a.tinv + 3 * (size_t)slot[g];
-                        q2[g] = sr[0];
-                        const float4 s1 = sr[1];
-                        cfx[g] = s1.x; cfy[g] = s1.y;
-                        q3[g] = make_float4(s1.z, s1.w, reinterpret_cast<const float*>(sr + 2)[0], 0.0f);
-                    } else {
-                        g0[g] = reinterpret_cast<const int4*>(a.geo + slot[g])[0];
-                        q3[g] = reinterpret_cast<const float4*>(a.geo + slot[g])[1];
-                    }
+                    g0[g] = reinterpret_cast<const int4*>(a.geo + slot[g])[0];
+                    q3[g] = reinterpret_cast<const float4*>(a.geo + slot[g])[1];
                     if (want_color) {
                         // vertex colours of a,b,c (RenderPass.vertices[RenderPass.indices[3p+k]].color), one 48-B record
                         if (EXT) {
@@ -2326,14 +2296,13 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
             }
 #pragma unroll
             for (int g = 0; g < NG; g++) {
-                if (miss[g] && !SHREC) {
+                if (miss[g]) {
                     int vx[3], vy[3];
                     decode_vertices(a.geo_full, slot[g], g0[g], q3[g], vx, vy);
                     if (METAL) {
                         metal_consts(vx, vy, q3[g].x, q3[g].y, q3[g].z, mt[g]);
                     } else {
-                        // T() of the winning primitive, recomputed (same function, same bits) — the sparse colour kernels read it
-                        // from the shade record instead (above)
+                        // T() of the winning primitive, recomputed (same function, same bits)
                         tinv_of(vx[0], vy[0], vx[1], vy[1], vx[2], vy[2], q2[g].x, q2[g].y, q2[g].z, q2[g].w);
                         cfx[g] = (float)vx[2] + 0.5f;
                         cfy[g] = (float)vy[2] + 0.5f;
@@ -2571,7 +2540,7 @@ static SetupArgs make_setup_args(const DeviceFrame& f) {
     SetupArgs a;
     a.tri_xyz = f.tri_xyz; a.box64 = f.box64; a.reordered = f.reordered; a.ntri = f.ntri;
     a.cull = f.live_parity >= 0 ? 1 : 0;
-    a.geo = f.geo; a.geo_full = f.geo_full; a.tinv = f.tinv;
+    a.geo = f.geo; a.geo_full = f.geo_full;
     a.tile_count = f.tile_count; a.ranges = f.ranges; a.tg = f.tg;
     a.metal = (f.flags & SWR_FLAG_METAL_RULES) ? 1 : 0;
     for (int c = 0; c < 4; c++)
@@ -2614,11 +2583,10 @@ hipError_t prepare_device() {
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)k_setup_hist<256, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-#define SWR_BIN_ATTR(MT, DF, AF, TI) \
-    if ((e = hipFuncSetAttribute((const void*)k_bin<256, MT, DF, AF, TI>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
-    SWR_BIN_ATTR(false, false, false, false) SWR_BIN_ATTR(true, false, false, false) SWR_BIN_ATTR(false, true, false, false) SWR_BIN_ATTR(true, true, false, false)
-    SWR_BIN_ATTR(false, false, true, false) SWR_BIN_ATTR(true, false, true, false) SWR_BIN_ATTR(false, true, true, false) SWR_BIN_ATTR(true, true, true, false)
-    SWR_BIN_ATTR(false, false, false, true) SWR_BIN_ATTR(false, true, false, true) SWR_BIN_ATTR(false, false, true, true) SWR_BIN_ATTR(false, true, true, true)
+#define SWR_BIN_ATTR(MT, DF, AF) \
+    if ((e = hipFuncSetAttribute((const void*)k_bin<256, MT, DF, AF>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    SWR_BIN_ATTR(false, false, false) SWR_BIN_ATTR(true, false, false) SWR_BIN_ATTR(false, true, false) SWR_BIN_ATTR(true, true, false)
+    SWR_BIN_ATTR(false, false, true) SWR_BIN_ATTR(true, false, true) SWR_BIN_ATTR(false, true, true) SWR_BIN_ATTR(true, true, true)
 #undef SWR_BIN_ATTR
     return hipFuncSetAttribute((const void*)k_fill_lds<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
@@ -2683,9 +2651,7 @@ bool launch_bin(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     const size_t lds = (size_t)((b.ntiles + 1) / 2) * 4 + (size_t)(b.per + 1) * 4 + 2 * (256 / 64) * 4 + 4;
     // the transform's last row is (0, 0, 0, 1): w == 1 for every finite vertex, no perspective divide (setup_triangle_r<.., AFF>)
     const bool aff = f.m[3] == 0.0f && f.m[7] == 0.0f && f.m[11] == 0.0f && f.m[15] == 1.0f;
-    const bool ti = b.a.tinv != nullptr && !b.a.metal;      // sparse colour frame under the CPU rules: a shade record per binned triangle for the resolve
-#define SWR_BIN_GO(MT, DF, AF, TI) SWR_LAUNCH(stop, (k_bin<256, MT, DF, AF, TI>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b)
-#define SWR_BIN_GO2(MT, DF, AF) do { if (!MT && ti) SWR_BIN_GO(false, DF, AF, true); else SWR_BIN_GO(MT, DF, AF, false); } while (0)
+#define SWR_BIN_GO2(MT, DF, AF) SWR_LAUNCH(stop, (k_bin<256, MT, DF, AF>), dim3(f.plan.G), dim3(256), (uint32_t)lds, s, b)
     if (aff) {
         if (b.defer_ok) { if (b.a.metal) SWR_BIN_GO2(true, true, true); else SWR_BIN_GO2(false, true, true); }
         else { if (b.a.metal) SWR_BIN_GO2(true, false, true); else SWR_BIN_GO2(false, false, true); }
@@ -2694,7 +2660,6 @@ bool launch_bin(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
         else { if (b.a.metal) SWR_BIN_GO2(true, false, false); else SWR_BIN_GO2(false, false, false); }
     }
 #undef SWR_BIN_GO2
-#undef SWR_BIN_GO
     return stop != nullptr;
 }
 
@@ -2733,13 +2698,6 @@ bool launch_sort_bins(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     return stop != nullptr;
 }
 
-// Does the resolve of this frame read shade records (so the binning stage has to write them)?  The sparse colour kernels
-// under the CPU rules with the reference's fragment stage (raster_tile, SHREC).
-bool frame_uses_shade_records(const DeviceFrame& f) {
-    const int64_t ntiles = (int64_t)f.tg.tiles_x * f.tg.tiles_y;
-    return !(f.flags & SWR_FLAG_NO_COLOR) && !(f.flags & SWR_FLAG_METAL_RULES) && f.material.shader == SWR_SHADER_PASSTHROUGH &&
-           f.ntri < 64 * ntiles;
-}
 // Does this frame take k_raster_depth (32-bit depth keys)?  Depth-only, z-tested, CPU rules, and the scene has not been moved
 // to the 64-bit kernel by the host (DeviceFrame::k32).
 bool frame_uses_k32(const DeviceFrame& f) {
@@ -2749,7 +2707,6 @@ bool frame_uses_k32(const DeviceFrame& f) {
 bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     RasterArgs a;
     a.geo = f.geo; a.geo_full = f.geo_full; a.tri_rgb = f.tri_rgb;
-    a.tinv = f.tinv;
     a.inv = f.inv; a.reordered = f.reordered;
     a.tri_nrm = f.tri_nrm;
     a.fs.shader = f.material.shader; a.fs.shininess_log2 = f.material.shininess_log2;

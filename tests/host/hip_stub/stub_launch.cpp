@@ -52,7 +52,6 @@ bool launch_sort_bins(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     fake_enqueue(s, nullptr, stop);
     return stop != nullptr;
 }
-bool frame_uses_shade_records(const DeviceFrame&) { return false; }
 bool frame_uses_k32(const DeviceFrame& f) {
     return f.k32 && (f.flags & SWR_FLAG_DEPTH_TEST) && (f.flags & SWR_FLAG_NO_COLOR) && !(f.flags & SWR_FLAG_METAL_RULES);
 }

@@ -121,10 +121,12 @@ __device__ __forceinline__ void edge_jump(int xa, int xb, int k, float rcp, Edge
     e.X = xa + sgn * q;
 }
 __device__ __forceinline__ void edge_next_row(EdgeStep& e) {
-    const int r2 = e.r + e.rs;
-    const bool c = r2 >= e.dy;
-    e.r = c ? r2 - e.dy : r2;
-    e.X += c ? e.ss1 : e.ss;
+    // (0 <= r < dy, 0 <= rs < dy: unsigned; the borrow of ONE subtraction is the comparison — five vector instructions per edge, not six)
+    const uint32_t r2 = (uint32_t)e.r + (uint32_t)e.rs;
+    uint32_t t;
+    const bool below = __builtin_sub_overflow(r2, (uint32_t)e.dy, &t);
+    e.r = (int)(below ? r2 : t);
+    e.X += below ? e.ss : e.ss1;
 }
 
 // Sorted integer vertices + chain data of one triangle, as the span walker needs them.
@@ -1246,6 +1248,15 @@ __device__ __forceinline__ unsigned long long lane_mask_le(int a, int b) {
     return __builtin_amdgcn_ballot_w64(a <= b);
 #endif
 }
+__device__ __forceinline__ unsigned long long lane_mask_ne(uint32_t a, uint32_t b) {
+#if SWR_ASM_MASKS
+    unsigned long long m;
+    asm("v_cmp_ne_u32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+    return m;
+#else
+    return __builtin_amdgcn_ballot_w64(a != b);
+#endif
+}
 __device__ __forceinline__ int bcast_i(int v, int src) { return __builtin_amdgcn_readlane(v, src); }
 __device__ __forceinline__ float bcast_f(float v, int src) {
     return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), src));
@@ -1693,7 +1704,7 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                                         __int_as_float((int)(((uint32_t)(t.cx - X0) & 0xFFFFu) | ((uint32_t)(t.cy - Y0) << 16))));
             }
             if (!K32) tabP[tid] = t.prim;
-            int y = mine ? ya : 1;
+            const int y = mine ? ya : 1;        // the first row; the walk itself counts in ebase (below)
             const int ye = mine ? yb : 0;
             uint32_t qhead = 0u, qcount = 0u;   // wave-uniform
             bool stolen = false;                // the next chunk has been chosen (wave-uniform)
@@ -1701,6 +1712,9 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
             // ring entry = owner lane | xl << 6 | yl << 12 | (pixels - 1) << 17, xl / yl tile-local
             static_assert(TILE_W == 64 && TILE_H == 32 && UNIT >= 1 && UNIT <= 8, "ring entry layout: 6 + 6 + 5 + 6 bits");
             uint32_t ebase = ((uint32_t)lane | ((uint32_t)((y - Y0) & (TILE_H - 1)) << 12)) - ((uint32_t)X0 << 6);
+            // the row counter is ebase itself (its y field grows by one per row): the walk ends at ebase_stop, the kink is at ebase_kink
+            const uint32_t ebase_stop = ebase + ((uint32_t)max(ye - y + 1, 0) << 12);
+            const uint32_t ebase_kink = ebase + ((uint32_t)(t.ch.s1y - y) << 12);       // (a kink above the first row is never met)
             // The two chains of draw(triangle:) (:276-277) as row steppers.  Left chain [S0,S1,S2]: the segment the
             // first row of the tile falls into, switched to [S1,S2] at the row y == S1.y (:469-475); right chain [S0,S2].
             // At y == S2.y the interpolant returns S2.x (:469-471): the stepper of [S1,S2] arrives there by itself
@@ -1860,7 +1874,7 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
             for (;;) {
                 // (lane masks straight from v_cmp: hipcc turns a ballot inside this loop into v_cndmask + v_cmp_ne on top
                 // of the compare; control flow is wave-uniform here, EXEC is all ones)
-                unsigned long long am = lane_mask_le(y, ye);                 // lanes with rows left
+                unsigned long long am = lane_mask_ne(ebase, ebase_stop);     // lanes with rows left
                 while (VAR != 4 && VAR != 10 && qcount < 64u && am != 0ull) {
                     int lo, hi;
                     if (METAL) {
@@ -1875,7 +1889,7 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                         EdgeStep nL = eL, nR = eR;
                         edge_next_row(nL);
                         edge_next_row(nR);
-                        if (y + 1 == s1y) nL = eK;
+                        if (ebase + (1u << 12) == ebase_kink) nL = eK;
                         lo = max(min(min(L0, nL.X), min(R0, nR.X)) - 1, bxa);
                         hi = min(max(max(L0, nL.X), max(R0, nR.X)), bxb);
                         if (__builtin_amdgcn_inverse_ballot_w64(am)) { eL = nL; eR = nR; }
@@ -1886,19 +1900,19 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                     // two single-compare ballots and a scalar AND: a ballot of (a && b) costs two more vector instructions
                     const unsigned long long pb = am & lane_mask_le(lo, hi);     // lanes with a non-empty span in this row
                     if (__builtin_amdgcn_inverse_ballot_w64(pb))
+                        // (hi - lo) << 17 | lo << 6, + ebase (which holds -X0 << 6): lo * (2^6 - 2^17) as one 24-bit multiply-add (0 <= lo < 2^23)
                         q[(qhead + qcount + rank_of(pb)) & (uint32_t)(QCAP - 1)] =
-                            ((uint32_t)(hi - lo) << 17) + (((uint32_t)lo << 6) + ebase);    // ebase holds -X0 << 6
+                            (uint32_t)__mul24(lo, 64 - (1 << 17)) + (((uint32_t)hi << 17) + ebase);
                     if (__builtin_amdgcn_inverse_ballot_w64(am)) {
-                        y += 1;
                         ebase += 1u << 12;
                         if (!METAL) {
                             edge_next_row(eL);
                             edge_next_row(eR);
-                            if (y == s1y) eL = eK;               // the kink: [S1,S2] starts at its first point
+                            if (ebase == ebase_kink) eL = eK;    // the kink: [S1,S2] starts at its first point
                         }
                     }
                     qcount += (uint32_t)__popcll(pb);
-                    am = lane_mask_le(y, ye);
+                    am = lane_mask_ne(ebase, ebase_stop);
                 }
                 if (SWR_STEAL_AHEAD && !stolen && am == 0ull) { stolen = true; steal_next(); }
                 if (qcount == 0u) break;

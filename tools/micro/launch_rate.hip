@@ -30,5 +30,21 @@ int main() {
                                "pair (328 B + 8 B) on one stream", "pair, stream per pair of four"};
         printf("%-34s enqueue %.2f us per launch-call   drained %.2f us\n", names[mode], (t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6);
     }
+    // the same through hipModuleLaunchKernel with the kernarg block handed over as one buffer (no per-argument marshalling, no host-function lookup)
+    hipFunction_t fn = nullptr;
+    if (hipGetFuncBySymbol(&fn, (const void*)k_null) == hipSuccess && fn) {
+        for (int mode = 0; mode < 2; mode++) {
+            size_t sz = sizeof(b);
+            void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &b, HIP_LAUNCH_PARAM_BUFFER_SIZE, &sz, HIP_LAUNCH_PARAM_END};
+            for (int i = 0; i < 2000; i++) hipModuleLaunchKernel(fn, 64, 1, 1, 256, 1, 1, 0, s[0], nullptr, extra);
+            hipDeviceSynchronize();
+            const double t0 = now();
+            for (int i = 0; i < N; i++) hipModuleLaunchKernel(fn, 64, 1, 1, 256, 1, 1, 0, mode ? s[i & 3] : s[0], nullptr, extra);
+            const double t1 = now();
+            hipDeviceSynchronize();
+            const double t2 = now();
+            printf("%-34s enqueue %.2f us per launch-call   drained %.2f us\n", mode ? "hipModuleLaunchKernel, four streams" : "hipModuleLaunchKernel, one stream", (t1 - t0) / N * 1e6, (t2 - t0) / N * 1e6);
+        }
+    } else printf("hipGetFuncBySymbol failed\n");
     return 0;
 }

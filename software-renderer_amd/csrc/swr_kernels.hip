@@ -1313,7 +1313,7 @@ __device__ __forceinline__ int wave_incl_add(int v) {
 // could not decide it.
 constexpr int VAR_ALLCOOP = 20;
 #ifndef SWR_RASTER_MIN_WAVES_EXT
-#define SWR_RASTER_MIN_WAVES_EXT 4   // the extended fragment stage's resolve (normal, uv, texels) needs > 96 VGPRs
+#define SWR_RASTER_MIN_WAVES_EXT 5   // (4 while the extended stage resolved per thread: > 96 VGPRs; with the winner table 5 waves fit: cfg5 textured 0.303 -> 0.283 ms)
 #endif
 #ifndef SWR_RASTER_MIN_WAVES
 #define SWR_RASTER_MIN_WAVES 5   // waves per SIMD the register allocator must allow (measured: 5 spill-free beats 6)
@@ -2220,21 +2220,16 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
         }
         if (!__any(zero_seen)) return false;    // (wave-uniform; no barrier follows)
     }
-    // A thread's two 4-pixel groups are resolved TOGETHER, pixel by pixel: the record / colour gathers of a new winner
-    // in group 0 and in group 1 are issued back to back and waited for once, so the chain a thread walks is four
-    // gather latencies instead of eight (colour frames: the wait for those gathers, not the arithmetic, is what the
-    // colour store costs over a depth-only frame — SQ_WAIT_ANY 73 M -> 146 M wave-cycles for +32 % VALU).
-    // Which kernels walk their two groups together is a measurement (profiles/r03/resolve_joint_ab.txt): it changes the
-    // register allocation of the whole kernel, and with it how many binning waves fit beside the raster's.
+    // The per-thread resolve: depth-only frames on the 64-bit keys (the Metal rules; scenes the host moved off the 32-bit keys;
+    // only the rare d == 0 winner is looked up), and the colour tiles the winner table above could not take.
+    // Depth-only: a thread's two 4-pixel groups are resolved TOGETHER, pixel by pixel: the gathers of a new winner in group 0 and
+    // in group 1 go out back to back and are waited for once (profiles/r03/resolve_joint_ab.txt).  Colour (cold path): one group
+    // at a time — the smaller register footprint.  (Rounds 2-3 chose per kernel, and the launch chose a joint walk for sparse
+    // colour scenes, template parameter NGX: all of that was tuning of what is now the cold path.)
 #ifndef SWR_NG_DEPTH
 #define SWR_NG_DEPTH 2
-#define SWR_NG_COLOR 1
-#define SWR_NG_METAL_COLOR 2
-#define SWR_NG_EXT 1
 #endif
-    // (NGX != 0: the launch chose — colour frames of SPARSE scenes, whose binning is short, take the joint walk: cfg5 0.198 -> 0.186 ms,
-    // cfg3 0.0422 -> 0.0408; cfg4's colour frames, 245 triangles per tile, lose 7 % with it beside their long k_bin)
-    constexpr int NG = NGX ? NGX : (EXT ? SWR_NG_EXT : (!COLOR ? SWR_NG_DEPTH : (METAL ? SWR_NG_METAL_COLOR : SWR_NG_COLOR)));
+    constexpr int NG = NGX ? NGX : (!COLOR ? SWR_NG_DEPTH : 1);
     static_assert(NG == 1 || NG == 2, "a thread owns two groups");
     for (int i0 = tid; VAR != 8 && VAR != 10 && VAR != 11 && i0 < TILE_W * TILE_H / 4; i0 += NG * RASTER_THREADS) {
         int ly[NG], lx[NG], y[NG], x[NG];
@@ -2260,7 +2255,10 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
             cfx[g] = cfy[g] = 0.0f;
             mt[g] = MetalTri{};
         }
-#pragma unroll
+        // (colour kernels reach this loop only for tiles the winner table could not take: kept small — one pixel at a time, pixels
+        // stored one by one — so that this cold path does not set the kernel's register count)
+        constexpr bool COLD = WTAB_OK;
+#pragma unroll(COLD ? 1 : 4)
         for (int k = 0; k < 4; k++) {
             uint32_t prim[NG];
             float d[NG];
@@ -2363,13 +2361,21 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                         c = (uint32_t)ub | ((uint32_t)ug << 8) | ((uint32_t)ur << 16) | ((uint32_t)ua << 24);
                     }
                 }
-                cpix[g][k] = c;
-                dpix[g][k] = d[g];
+                if constexpr (COLD) {
+                    if (on[g] && x[g] + k <= X1) {
+                        const size_t at1 = (size_t)(y[g] - a.tg.row_begin) * (size_t)W + (size_t)(x[g] + k);
+                        reinterpret_cast<uint32_t*>(a.color)[at1] = c;
+                        a.depth[at1] = d[g];
+                    }
+                } else {
+                    cpix[g][k] = c;
+                    dpix[g][k] = d[g];
+                }
             }
         }
 #pragma unroll
         for (int g = 0; g < NG; g++) {
-            if (!on[g]) continue;
+            if (COLD || !on[g]) continue;
             const size_t at = (size_t)(y[g] - a.tg.row_begin) * (size_t)W + (size_t)x[g];   // App.swift:351-360
             if (vec_ok && x[g] + 3 <= X1) {
                 // streaming stores: nothing on the GPU reads the framebuffer again, and 33 MB of dirty lines left in the
@@ -2778,16 +2784,11 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     }
 #endif
     if (f.flags & SWR_FLAG_DEPTH_TEST) {
-        // colour frames of sparse scenes (fewer than 64 primitives per tile on average: BASELINE configs 2, 3, 5) resolve their
-        // two groups together (raster_tile, NGX)
-        const bool sparse = f.ntri < (int64_t)64 * ntiles;
-        if (a.color && sparse) SWR_LAUNCH(stop, (k_raster<true, 0, false, true, 2>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-        else if (a.color) SWR_LAUNCH(stop, (k_raster<true, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        if (a.color) SWR_LAUNCH(stop, (k_raster<true, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else if (frame_uses_k32(f)) SWR_LAUNCH(stop, k_raster_depth, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else SWR_LAUNCH(stop, (k_raster<true, 0, false, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
     } else {
-        if (a.color && f.ntri < (int64_t)64 * ntiles) SWR_LAUNCH(stop, (k_raster<false, 0, false, true, 2>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-        else if (a.color) SWR_LAUNCH(stop, (k_raster<false, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        if (a.color) SWR_LAUNCH(stop, (k_raster<false, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else SWR_LAUNCH(stop, (k_raster<false, 0, false, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
     }
     return stop != nullptr;

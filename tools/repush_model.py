@@ -215,3 +215,20 @@ for carry, pw in ((0, 2), (16, 2), (32, 2), (63, 2), (16, 1)):
     ps, cs = sim_carry(chunks, 4, carry, pw)
     sc_ = total_chunks / len(chunks)
     print(f"  carry <= {carry:2d} entries, {pw} chunks per wave: producer {ps * sc_ / 1e3:.1f} K, consumer steps {cs * sc_ / 1e3:.1f} K")
+
+# ---- visit size chosen per chunk (2 / 4 / 8 pixels per lane per visit): consumer cost = visits x (OVH + PX x UPX) wave-instructions
+OVH, PX = 25, 13
+tot = {2: 0, 4: 0, 8: 0, "best": 0}
+pick = {2: 0, 4: 0, 8: 0}
+for lanes in chunks:
+    c = {}
+    for U in (2, 4, 8):
+        _, cs, _, _ = sim_repush(lanes, U, False, True)
+        c[U] = cs * (OVH + PX * U)
+        tot[U] += c[U]
+    b = min(c, key=c.get)
+    pick[b] += 1
+    tot["best"] += c[b]
+sc = total_chunks / len(chunks) / 1e6
+print(f"  consumer wave-instructions (model: {OVH} per visit + {PX} per pixel slot): UPX 2: {tot[2]*sc:.2f} M  4: {tot[4]*sc:.2f} M  8: {tot[8]*sc:.2f} M  "
+      f"best per chunk: {tot['best']*sc:.2f} M  (chunks choosing 2 / 4 / 8: {pick[2]} / {pick[4]} / {pick[8]})")

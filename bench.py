@@ -82,11 +82,28 @@ def cpu_baseline(scene, budget_s: float = 15.0):
         frames += 1
     t = float(np.median(times[1:])) if len(times) > 1 else times[0]
     mpix = scene.width * scene.height / t / 1e6
-    return {"value": round(mpix, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
-            "sample": f"{frames} whole frames of the same workload ({scene.triangles} triangles, "
-                      f"{scene.width}x{scene.height}, flags={scene.flags}); median of frames 2..{frames}; "
-                      f"{st.fragments} fragments/frame",
-            "ms_per_frame": round(t * 1e3, 2), "host_cpus": os.cpu_count()}
+    out = {"value": round(mpix, 3), "unit": "Mpixels/s", "cores": 1, "kind": "port",
+           "sample": f"{frames} whole frames of the same workload ({scene.triangles} triangles, "
+                     f"{scene.width}x{scene.height}, flags={scene.flags}); median of frames 2..{frames}; "
+                     f"{st.fragments} fragments/frame",
+           "ms_per_frame": round(t * 1e3, 2), "host_cpus": os.cpu_count()}
+    # SURVEY 8(d) (ii), optional: the same oracle on row bands, one thread per band (the reference itself is single-threaded: `value`
+    # above stays the faithful figure).  16 threads: a one-GPU box's share of its host.
+    try:
+        nthr = max(2, min(16, os.cpu_count() or 2))
+        tt = []
+        for _ in range(4):
+            t0 = time.perf_counter()
+            _, _, rcs = oracle.render_threads(scene, nthr)
+            assert not any(rcs)
+            tt.append(time.perf_counter() - t0)
+        tb = float(np.median(tt[1:]))
+        out["row_bands"] = {"value": round(scene.width * scene.height / tb / 1e6, 2), "unit": "Mpixels/s", "cores": nthr,
+                            "ms_per_frame": round(tb * 1e3, 2),
+                            "sample": "4 whole frames, one oracle thread per row band (every thread sets up every triangle); median of frames 2..4"}
+    except Exception as e:                                     # optional leg: never fails the bench line
+        out["row_bands"] = {"error": str(e)[:200]}
+    return out
 
 
 def main():

@@ -1643,7 +1643,7 @@ void sub_band(int64_t row_begin, int64_t row_end, int n, int k, int64_t* r0, int
 extern "C" {
 
 int swr_abi_version(void) { return SWR_ABI_VERSION; }
-const char* swr_version(void) { return "swr-hip gfx950 0.3 (tile 64x32, wave64 LDS visibility keys, span ring, one-launch binning, multi-device bands)"; }
+const char* swr_version(void) { return "swr-hip gfx950 0.4 (tile 64x32, wave64 LDS visibility keys: 32-bit depth keys + winner table, span ring, one-launch binning, frame lanes, multi-device bands)"; }
 int swr_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }

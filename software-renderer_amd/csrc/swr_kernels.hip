@@ -1284,6 +1284,26 @@ __device__ __forceinline__ bool metal_weights(const MetalTri& m, int x, int y, f
     return 0.0f <= w0 && w0 <= 1.0f && 0.0f <= w1 && w1 <= 1.0f && 0.0f <= w2 && w2 <= 1.0f;   // :153
 }
 
+// The same two quotients with the divisor's share of the work done once (the winner table's shading pass): the division sequence of
+// tinv_of — reciprocal, one Newton step, quotient, two residual corrections, v_div_fixup — whose argument holds here too: the divider
+// is an integer-valued float below 2^62 in magnitude (or 0: fix-up gives the inf / NaN that '/' gives), the numerators are sums of two
+// products of such values, nothing needs scaling.  Correctly rounded, bit for bit what metal_weights computes (every Metal-rules test
+// with colour goes through here).
+__device__ __forceinline__ void metal_weights_shared_rcp(const MetalTri& m, int x, int y, float& w0, float& w1, float& w2) {
+    const float sx = (float)x + 0.5f, sy = (float)y + 0.5f;                       // :133
+    const float rc0 = __builtin_amdgcn_rcpf(m.divider);
+    const float rcp = __builtin_fmaf(__builtin_fmaf(-m.divider, rc0, 1.0f), rc0, rc0);
+    auto div_exact = [&](float n) {
+        const float q0 = n * rcp;
+        const float q1 = __builtin_fmaf(__builtin_fmaf(-m.divider, q0, n), rcp, q0);
+        const float q2 = __builtin_fmaf(__builtin_fmaf(-m.divider, q1, n), rcp, q1);
+        return __builtin_amdgcn_div_fixupf(q2, m.divider, n);
+    };
+    w0 = div_exact(m.A0 * (sx - m.p3x) + m.B0 * (sy - m.p3y));                    // :144-145
+    w1 = div_exact(m.A1 * (sx - m.p3x) + m.B1 * (sy - m.p3y));                    // :147-148
+    w2 = 1.0f - w0 - w1;                                                          // :149
+}
+
 // ---- wave64 scans on DPP (all 64 lanes must be active) ---------------------------------------
 template <int CTRL, int ROWMASK>
 __device__ __forceinline__ int dpp0(int v) {
@@ -1332,7 +1352,7 @@ constexpr int VAR_ALLCOOP = 20;
 #endif
 // K32: 32-bit depth keys (RasterLds32).  Returns true (workgroup-uniform) when the tile has to be rastered again with the
 // 64-bit keys — only a K32 instance ever does.
-template <bool ZTEST, int VAR, bool METAL, bool EXT, bool COLOR, int NGX = 0, bool K32 = false>
+template <bool ZTEST, int VAR, bool METAL, bool EXT, bool COLOR, bool PLAIN = false, bool K32 = false>
 __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::conditional<K32, RasterLds32, RasterLds64>::type& L) {
     static_assert(!METAL || ZTEST, "the Metal rules always z-test");
     static_assert(!EXT || COLOR, "the extended fragment stage only exists for colour frames");
@@ -1394,7 +1414,8 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
     const uint32_t bin_mask = a.tag_class ? (1u << CLASS_SHIFT) - 1u : 0xFFFFFFFFu;
     // Colour frames with the reference's fragment stage: the key's low word also carries the triangle's position in this bin
     // (below the original index, which still decides ties), so the resolve can set up every WINNER once — see "winner table" there.
-    constexpr bool WTAB_OK = COLOR && !K32 && VAR == 0;
+    // (PLAIN: the kernels for scenes of more than 2^20 primitives — no room for the bin position in the key: the per-thread resolve)
+    constexpr bool WTAB_OK = COLOR && !K32 && VAR == 0 && !PLAIN;
     const bool wtab = WTAB_OK && a.pack_local != 0 && m <= (1u << WTAB_LOCAL_BITS);      // (workgroup-uniform)
 
     // the gather chain of the first batch (bin entry -> record) is issued before the LDS init so
@@ -2033,7 +2054,7 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                 }
             };
             // the first 256 bin entries' gathers go out now and land while the pixels are looked at
-            const uint32_t slot_first = (uint32_t)tid < m ? a.bins[b0 + (uint32_t)tid] & bin_mask : 0u;
+            uint32_t slot_first = (uint32_t)tid < m ? a.bins[b0 + (uint32_t)tid] & bin_mask : 0u;
             Gathered G_first = gather(slot_first);
             // 1: position of every pixel's winner (0xFFFF: none) ...
             uint32_t pos[2][4];
@@ -2085,17 +2106,71 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                 const uint2 wv = L.winners[q >> 5];
                 return wv.y + (uint32_t)__popc(wv.x & ((1u << (q & 31u)) - 1u));
             };
-            if (nrec <= (uint32_t)WTAB_RCAP) {
-                // 2: one lane per bin entry (that owns a pixel): its record
-                uint32_t slot = slot_first;
+            // one pixel from record rid
+            auto shade = [&](uint32_t rid, int x, int y, uint32_t& c, float& d) {
+                const float* r = recs + rid * REC_STRIDE;
+                float v[REC_F];
+#pragma unroll
+                for (int j = 0; j < REC_F; j++) v[j] = r[j];
+                float w0, w1, w2;
+                if (METAL) {
+                    MetalTri mt;
+                    mt.p3x = v[0]; mt.p3y = v[1]; mt.A0 = v[2]; mt.B0 = v[3]; mt.A1 = v[4]; mt.B1 = v[5]; mt.divider = v[6];
+                    mt.z0 = v[7]; mt.z1 = v[8]; mt.z2 = v[9];
+                    metal_weights_shared_rcp(mt, x, y, w0, w1, w2);           // Shaders.metal:133-149
+                } else {
+                    const float dx = ((float)x + 0.5f) - v[4];
+                    const float dy = ((float)y + 0.5f) - v[5];
+                    w0 = v[0] * dx + v[1] * dy;
+                    w1 = v[2] * dx + v[3] * dy;
+                    w2 = 1.0f - w0 - w1;
+                }
+                d = INFINITY;                                                 // (:206; painter's order leaves the depth image alone)
+                if (ZTEST) d = v[7] * w0 + v[8] * w1 + v[9] * w2;              // :257
+                VertexOut vin;
+                vin.pos = make_float4((float)x + 0.5f, (float)y + 0.5f, d, 1.0f);
+                vin.color = make_float3(v[10] * w0 + v[13] * w1 + v[16] * w2,     // :266
+                                        v[11] * w0 + v[14] * w1 + v[17] * w2,
+                                        v[12] * w0 + v[15] * w1 + v[18] * w2);
+                float4 f;
+                if constexpr (EXT) {   // varyings interpolated like colour
+                    vin.normal = make_float3(v[19] * w0 + v[22] * w1 + v[25] * w2,
+                                             v[20] * w0 + v[23] * w1 + v[26] * w2,
+                                             v[21] * w0 + v[24] * w1 + v[27] * w2);
+                    vin.uv = make_float2(v[28] * w0 + v[30] * w1 + v[32] * w2,
+                                         v[29] * w0 + v[31] * w1 + v[33] * w2);
+                    f = fragment_shader(vin, a.fs);
+                } else {
+                    f = fragment_shader(vin);
+                }
+                // Pixel(float3:) -> .floats(b: z, g: y, r: x, a: 1) truncates (:116-128); the Metal path's bgra8Unorm store rounds to nearest even
+                float ub = fminf(fmaxf(f.z, 0.0f), 1.0f) * 255.0f, ug = fminf(fmaxf(f.y, 0.0f), 1.0f) * 255.0f;
+                float ur = fminf(fmaxf(f.x, 0.0f), 1.0f) * 255.0f, ua = fminf(fmaxf(f.w, 0.0f), 1.0f) * 255.0f;
+                if (METAL) { ub = rintf(ub); ug = rintf(ug); ur = rintf(ur); ua = rintf(ua); }
+                c = (uint32_t)ub | ((uint32_t)ug << 8) | ((uint32_t)ur << 16) | ((uint32_t)ua << 24);
+            };
+            // 2: one lane per bin entry (that owns a pixel) whose record number falls into [base, base + WTAB_RCAP): its record
+            // (FIRST: the only round of the tile — the records of the first 256 entries have been gathered already)
+            auto build_round = [&](uint32_t base, auto FIRSTc) {
+                constexpr bool FIRST = decltype(FIRSTc)::value;
                 for (uint32_t i = (uint32_t)tid; i < m; i += RASTER_THREADS) {
                     const bool mine = direct || ((L.winners[i >> 5].x >> (i & 31u)) & 1u);
-                    if (i >= (uint32_t)RASTER_THREADS && mine) {
-                        slot = a.bins[b0 + i] & bin_mask;
-                        G_first = gather(slot);
+                    const uint32_t rid = mine ? rid_of(i) - base : 0xFFFFFFFFu;
+                    if (rid >= (uint32_t)WTAB_RCAP) continue;
+                    if constexpr (FIRST) {           // (one call of build: the gathered record of the first pass, or this pass's, in the same registers)
+                        if (i >= (uint32_t)RASTER_THREADS) {
+                            slot_first = a.bins[b0 + i] & bin_mask;
+                            G_first = gather(slot_first);
+                        }
+                        build(rid, slot_first, G_first);
+                    } else {
+                        const uint32_t slot = a.bins[b0 + i] & bin_mask;
+                        build(rid, slot, gather(slot));
                     }
-                    if (mine) build(rid_of(i), slot, G_first);
                 }
+            };
+            if (nrec <= (uint32_t)WTAB_RCAP) {
+                build_round(0u, std::true_type{});
                 __syncthreads();
                 // 3: every pixel from its winner's record
 #pragma unroll 1
@@ -2110,52 +2185,9 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                     float dpix[4];
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
-                        uint32_t c = 0u;               // Pixel(0,0,0,0) (:205)
-                        float d = INFINITY;            // (:206)
-                        if (ps[k] != 0xFFFFu && x + k <= X1) {
-                            const float* r = recs + rid_of(ps[k]) * REC_STRIDE;
-                            float v[REC_F];
-#pragma unroll
-                            for (int j = 0; j < REC_F; j++) v[j] = r[j];
-                            float w0, w1, w2;
-                            if (METAL) {
-                                MetalTri mt;
-                                mt.p3x = v[0]; mt.p3y = v[1]; mt.A0 = v[2]; mt.B0 = v[3]; mt.A1 = v[4]; mt.B1 = v[5]; mt.divider = v[6];
-                                mt.z0 = v[7]; mt.z1 = v[8]; mt.z2 = v[9];
-                                metal_weights(mt, x + k, y, w0, w1, w2);                  // Shaders.metal:133-149
-                            } else {
-                                const float dx = ((float)(x + k) + 0.5f) - v[4];
-                                const float dy = ((float)y + 0.5f) - v[5];
-                                w0 = v[0] * dx + v[1] * dy;
-                                w1 = v[2] * dx + v[3] * dy;
-                                w2 = 1.0f - w0 - w1;
-                            }
-                            if (ZTEST) d = v[7] * w0 + v[8] * w1 + v[9] * w2;              // :257
-                            VertexOut vin;
-                            vin.pos = make_float4((float)(x + k) + 0.5f, (float)y + 0.5f, d, 1.0f);
-                            vin.color = make_float3(v[10] * w0 + v[13] * w1 + v[16] * w2,     // :266
-                                                    v[11] * w0 + v[14] * w1 + v[17] * w2,
-                                                    v[12] * w0 + v[15] * w1 + v[18] * w2);
-                            float4 f;
-                            if constexpr (EXT) {   // varyings interpolated like colour
-                                vin.normal = make_float3(v[19] * w0 + v[22] * w1 + v[25] * w2,
-                                                         v[20] * w0 + v[23] * w1 + v[26] * w2,
-                                                         v[21] * w0 + v[24] * w1 + v[27] * w2);
-                                vin.uv = make_float2(v[28] * w0 + v[30] * w1 + v[32] * w2,
-                                                     v[29] * w0 + v[31] * w1 + v[33] * w2);
-                                f = fragment_shader(vin, a.fs);
-                            } else {
-                                f = fragment_shader(vin);
-                            }
-                            // Pixel(float3:) -> .floats(b: z, g: y, r: x, a: 1) truncates (:116-128);
-                            // the Metal path's bgra8Unorm store rounds to nearest even
-                            float ub = fminf(fmaxf(f.z, 0.0f), 1.0f) * 255.0f, ug = fminf(fmaxf(f.y, 0.0f), 1.0f) * 255.0f;
-                            float ur = fminf(fmaxf(f.x, 0.0f), 1.0f) * 255.0f, ua = fminf(fmaxf(f.w, 0.0f), 1.0f) * 255.0f;
-                            if (METAL) { ub = rintf(ub); ug = rintf(ug); ur = rintf(ur); ua = rintf(ua); }
-                            c = (uint32_t)ub | ((uint32_t)ug << 8) | ((uint32_t)ur << 16) | ((uint32_t)ua << 24);
-                        }
-                        cpix[k] = c;
-                        dpix[k] = d;
+                        cpix[k] = 0u;                  // Pixel(0,0,0,0) (:205)
+                        dpix[k] = INFINITY;            // (:206)
+                        if (ps[k] != 0xFFFFu && x + k <= X1) shade(rid_of(ps[k]), x + k, y, cpix[k], dpix[k]);
                     }
                     const size_t at = (size_t)(y - a.tg.row_begin) * (size_t)W + (size_t)x;   // App.swift:351-360
                     if (vec_ok && x + 3 <= X1) {
@@ -2174,6 +2206,32 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                 }
                 return false;
             }
+            // More winners than records fit (a tile of ~1 000 two-pixel triangles has ~600): rounds of WTAB_RCAP winners, every pixel
+            // stored by the round its winner falls into (and the pixels without one by the first) — one pixel at a time, small code.
+            for (uint32_t base = 0u; base < nrec; base += (uint32_t)WTAB_RCAP) {
+                if (base) __syncthreads();       // the round before has read its records
+                build_round(base, std::false_type{});
+                __syncthreads();
+#pragma unroll 1
+                for (int p = tid; p < TILE_W * TILE_H; p += RASTER_THREADS) {     // (consecutive lanes = consecutive pixels: coalesced 4-B stores)
+                    const int y = Y0 + p / TILE_W, x = X0 + p % TILE_W;
+                    if (y < Yp0 || y > Yp1 || x > X1) continue;
+                    const uint32_t q = pix[p];
+                    uint32_t c = 0u;                   // Pixel(0,0,0,0) (:205)
+                    float d = INFINITY;                // (:206)
+                    bool store = q == 0xFFFFu && base == 0u;
+                    if (q != 0xFFFFu) {
+                        const uint32_t rid = rid_of(q) - base;
+                        if (rid < (uint32_t)WTAB_RCAP) { shade(rid, x, y, c, d); store = true; }
+                    }
+                    if (store) {
+                        const size_t at = (size_t)(y - a.tg.row_begin) * (size_t)W + (size_t)x;
+                        reinterpret_cast<uint32_t*>(a.color)[at] = c;
+                        a.depth[at] = d;
+                    }
+                }
+            }
+            return false;
         }
     }
     // Colour frames: the stream slots of ALL this thread's winners first (original index -> slot is a gather from a
@@ -2229,7 +2287,7 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
 #ifndef SWR_NG_DEPTH
 #define SWR_NG_DEPTH 2
 #endif
-    constexpr int NG = NGX ? NGX : (!COLOR ? SWR_NG_DEPTH : 1);
+    constexpr int NG = !COLOR ? SWR_NG_DEPTH : ((PLAIN && METAL && !EXT) ? 2 : 1);
     static_assert(NG == 1 || NG == 2, "a thread owns two groups");
     for (int i0 = tid; VAR != 8 && VAR != 10 && VAR != 11 && i0 < TILE_W * TILE_H / 4; i0 += NG * RASTER_THREADS) {
         int ly[NG], lx[NG], y[NG], x[NG];
@@ -2401,19 +2459,19 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
 }
 
 // The kernels proper: the reference's fragment stage — colour and depth-only frames (SWR_FLAG_NO_COLOR) as separate kernels, so
-// that each has its own register allocation (tools/vgprs.sh: 86 depth-only, 91 colour, 88 Metal rules; the budget of 88 above is
-// the depth-only kernel's) — and the extended one (its resolve needs more).
-template <bool ZTEST, int VAR = 0, bool METAL = false, bool COLOR = false, int NGX = 0>
+// that each has its own register allocation (tools/vgprs.sh: 86 depth-only, 87 colour, 88 Metal rules; the budget of 88 above) —
+// and the extended one.  PLAIN = the colour kernels of scenes with more than 2^20 primitives (no winner table: raster_tile).
+template <bool ZTEST, int VAR = 0, bool METAL = false, bool COLOR = false, bool PLAIN = false>
 __global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES) __attribute__((amdgpu_num_vgpr(SWR_RASTER_VGPRS)))
 void k_raster(RasterArgs a) {
     __shared__ RasterLds64 L;
-    raster_tile<ZTEST, VAR, METAL, false, COLOR, NGX>(a, L);
+    raster_tile<ZTEST, VAR, METAL, false, COLOR, PLAIN>(a, L);
 }
-template <bool ZTEST, bool METAL = false>
-__global__ __launch_bounds__(RASTER_THREADS, SWR_RASTER_MIN_WAVES_EXT)
+template <bool ZTEST, bool METAL = false, bool PLAIN = false>
+__global__ __launch_bounds__(RASTER_THREADS, PLAIN ? 4 : SWR_RASTER_MIN_WAVES_EXT)
 void k_raster_ext(RasterArgs a) {
     __shared__ RasterLds64 L;
-    raster_tile<ZTEST, 0, METAL, true, true>(a, L);
+    raster_tile<ZTEST, 0, METAL, true, true, PLAIN>(a, L);
 }
 // Depth-only z-tested frames under the CPU rules: 32-bit keys first; the rare tile whose result they cannot vouch for (a
 // zero, whose sign is the first-drawn winner's) is rastered again, by the same workgroup, with the 64-bit keys.  One LDS block for both.
@@ -2422,9 +2480,9 @@ void k_raster_depth(RasterArgs a) {
     constexpr size_t BYTES = sizeof(RasterLds64) > sizeof(RasterLds32) ? sizeof(RasterLds64) : sizeof(RasterLds32);
     __shared__ __attribute__((aligned(16))) unsigned char raw[BYTES];
     if (blockIdx.x == 0 && threadIdx.x == 0) *a.host_redo = atomicExch(a.redo_dev, 0u);     // what the launches before this one counted
-    if (raster_tile<true, 0, false, false, false, 0, true>(a, *reinterpret_cast<RasterLds32*>(raw))) {
+    if (raster_tile<true, 0, false, false, false, false, true>(a, *reinterpret_cast<RasterLds32*>(raw))) {
         if (threadIdx.x == 0 && blockIdx.x % REDO_SAMPLE == 0) atomicAdd(a.redo_dev, 1u);
-        raster_tile<true, VAR_ALLCOOP, false, false, false, 0, false>(a, *reinterpret_cast<RasterLds64*>(raw));
+        raster_tile<true, VAR_ALLCOOP, false, false, false, false, false>(a, *reinterpret_cast<RasterLds64*>(raw));
     }
 }
 
@@ -2745,6 +2803,7 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     a.redo_dev = f.redo_dev; a.host_redo = f.host_redo;
     a.insort = f.insort;
     a.pack_local = f.ntri <= (1ll << WTAB_PRIM_BITS) ? 1 : 0;
+    const bool plain = !a.pack_local;      // more than 2^20 primitives: the colour kernels without the winner table
     const unsigned ntiles = (unsigned)(f.tg.tiles_x * f.tg.tiles_y);
     if (ntiles == 0) return false;
     // Small grids (a small window: the reference app's 512x512 is 128 tiles): four workgroups fit where one tile's
@@ -2758,16 +2817,21 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     const unsigned tiles = ntiles << a.vs_log;
     const bool ext = f.material.shader != SWR_SHADER_PASSTHROUGH && a.color != nullptr;
     if (f.flags & SWR_FLAG_METAL_RULES) {
-        if (ext) SWR_LAUNCH(stop, (k_raster_ext<true, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        if (ext && plain) SWR_LAUNCH(stop, (k_raster_ext<true, true, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        else if (ext) SWR_LAUNCH(stop, (k_raster_ext<true, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        else if (a.color && plain) SWR_LAUNCH(stop, (k_raster<true, 0, true, true, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else if (a.color) SWR_LAUNCH(stop, (k_raster<true, 0, true, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else SWR_LAUNCH(stop, (k_raster<true, 0, true, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         return stop != nullptr;
     }
     if (ext) {
-        if (f.flags & SWR_FLAG_DEPTH_TEST)
-            SWR_LAUNCH(stop, (k_raster_ext<true, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
-        else
-            SWR_LAUNCH(stop, (k_raster_ext<false, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        if (f.flags & SWR_FLAG_DEPTH_TEST) {
+            if (plain) SWR_LAUNCH(stop, (k_raster_ext<true, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+            else SWR_LAUNCH(stop, (k_raster_ext<true, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        } else {
+            if (plain) SWR_LAUNCH(stop, (k_raster_ext<false, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+            else SWR_LAUNCH(stop, (k_raster_ext<false, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        }
         return stop != nullptr;
     }
 #ifdef SWR_ABLATION
@@ -2784,11 +2848,13 @@ bool launch_raster(const DeviceFrame& f, hipStream_t s, hipEvent_t stop) {
     }
 #endif
     if (f.flags & SWR_FLAG_DEPTH_TEST) {
-        if (a.color) SWR_LAUNCH(stop, (k_raster<true, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        if (a.color && plain) SWR_LAUNCH(stop, (k_raster<true, 0, false, true, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        else if (a.color) SWR_LAUNCH(stop, (k_raster<true, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else if (frame_uses_k32(f)) SWR_LAUNCH(stop, k_raster_depth, dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else SWR_LAUNCH(stop, (k_raster<true, 0, false, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
     } else {
-        if (a.color) SWR_LAUNCH(stop, (k_raster<false, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        if (a.color && plain) SWR_LAUNCH(stop, (k_raster<false, 0, false, true, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
+        else if (a.color) SWR_LAUNCH(stop, (k_raster<false, 0, false, true>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
         else SWR_LAUNCH(stop, (k_raster<false, 0, false, false>), dim3(tiles), dim3(RASTER_THREADS), 0, s, a);
     }
     return stop != nullptr;

@@ -341,3 +341,16 @@ def test_gpu_winner_table_in_bands_and_small_windows(swr, oracle):
         with swr.Context(0, device_count=bands) as ctx:
             c, d = ctx.render(s.vertices, s.indices, s.transform, s.width, s.height, DT)
             assert_same(c, d, ref_c, ref_d, f"{bands} band(s)")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("flags,shader", [(DT, 0), (0, 0), (METAL, 0), (DT, 2), (METAL, 1)])
+def test_gpu_colour_kernels_of_scenes_beyond_2_to_20_primitives(gpu_ctx, oracle, swr, flags, shader):
+    """More than 2^20 primitives: no room for the bin position beside the original index in the key — the colour kernels without
+    the winner table (k_raster<.., PLAIN>, k_raster_ext<.., PLAIN>)."""
+    s = swr.scenes.random_soup((1 << 20) + 4099, 1280, 720, 515 + shader, r_ndc=0.006, flags=flags, margin=1.02)
+    sh = swr.scenes.random_shading(s.vertices.shape[0], 5 + shader, shader, shininess_log2=2) if shader else None
+    ref_c, ref_d, _, rc = oracle_frame(oracle, s, flags, sh)
+    assert rc == 0
+    c, d = gpu_ctx.render(s.vertices, s.indices, s.transform, s.width, s.height, flags, shading=sh)
+    assert_same(c, d, ref_c, ref_d, f"2^20 + 4099 triangles, flags {flags}, shader {shader}")

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Alternating A/B of library builds on one box: python tools/ab.py [--scene cfg4|cfg4c|cfg5|cfg3|metal|metalc|cfg5t|cfg3p] [--reps 3] lib/a.so lib/b.so ...
+"""Alternating A/B of library builds on one box: python tools/ab.py [--scene cfg4|cfg4c|cfg5|cfg3|metal|metalc|cfg5t|cfg3p|micro|micro2] [--reps 3] lib/a.so lib/b.so ...
 Per build: pipelined ms/frame (300 untimed frames), k_raster alone (pipelining off, events around the kernel)."""
 import os, subprocess, sys, json
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -12,6 +12,8 @@ name = sys.argv[1]
 sc = {"cfg4": lambda: S.cfg4_soup(), "cfg4c": lambda: S.cfg4_soup(depth_only=False), "cfg5": lambda: S.cfg5_sponza_scale(),
       "cfg3": lambda: S.cfg3_bunny_scale(), "cfg2": lambda: S.cfg2_teapot_scale(), "metal": lambda: S.cfg4_soup(),
       "metalc": lambda: S.cfg4_soup(depth_only=False), "cfg5t": lambda: S.cfg5_textured(), "cfg3p": lambda: S.cfg3_phong(),
+      "micro": lambda: S.cfg4_soup(ntri=1_000_000, width=1920, height=1080, r_ndc=0.004, depth_only=False),   # ~1000 two-pixel triangles per tile
+      "micro2": lambda: S.cfg4_soup(ntri=500_000, width=1920, height=1080, r_ndc=0.008, depth_only=False),
       "occluded": lambda: S.occluded_soup(z_occluder=0.5), "occluded_near": lambda: S.occluded_soup(z_occluder=0.1)}[name]()
 flags = S.FLAG_METAL_RULES | S.FLAG_NO_COLOR if name == "metal" else (S.FLAG_METAL_RULES if name == "metalc" else sc.flags)
 with swr_amd.Context() as ctx:

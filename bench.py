@@ -66,6 +66,20 @@ def load_profile_json(name):
     return None
 
 
+def csrc_digest():
+    """sha256 (first 16 hex digits) over the kernel sources the library is built from: profiles/traffic.json and valu.json carry
+    the digest of the sources they were measured on (tools/profiles_from_refresh.py), so the bench line can say whether the static
+    counters it quotes belong to the code that is running (there is no .git on the GPU box)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "software-renderer_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*"))):
+        with open(f, "rb") as fh:
+            h.update(os.path.basename(f).encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(scene, budget_s: float = 15.0):
     """The oracle (kind 'port': C restatement of Renderer.swift, per-pixel 2x2 inverse kept,
     single thread like the reference) on whole frames of the same workload."""
@@ -269,6 +283,8 @@ def main():
         "traffic": traffic.get("k_raster_bytes_per_launch") if n_gpus == 1 else None,
         "traffic_source": "profiles/traffic.json (rocprofv3 --pmc passes of tools/profile.sh on this workload; static, not re-measured in this run)",
         "traffic_measured_on": traffic.get("commit"),
+        # do the static counters (traffic, valu.insts) belong to the kernel sources this library was built from?
+        "static_counters_match_sources": (traffic.get("csrc_digest") == csrc_digest()) if traffic.get("csrc_digest") else None,
         "algorithmic_bytes_per_launch": largest_band_px * bytes_per_px,
         "avg_launch_ms": round(raster_ms, 5), "launches_timed": frames, "timed_every_nth_launch": SAMPLE,
         "ms_per_step_while_sampling": round(dt_s / roof_steps * 1e3, 4),

@@ -2149,28 +2149,23 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                 if (METAL) { ub = rintf(ub); ug = rintf(ug); ur = rintf(ur); ua = rintf(ua); }
                 c = (uint32_t)ub | ((uint32_t)ug << 8) | ((uint32_t)ur << 16) | ((uint32_t)ua << 24);
             };
-            // 2: one lane per bin entry (that owns a pixel) whose record number falls into [base, base + WTAB_RCAP): its record
-            // (FIRST: the only round of the tile — the records of the first 256 entries have been gathered already)
-            auto build_round = [&](uint32_t base, auto FIRSTc) {
-                constexpr bool FIRST = decltype(FIRSTc)::value;
+            // Passes 2 and 3, in ROUNDS of WTAB_RCAP winners: one round for every tile of the BASELINE scenes; a tile of ~1 000 two-pixel
+            // triangles has ~600 winners and takes two.  A pixel is shaded and stored by the round its winner's number falls into
+            // (pixels without a winner by the first); a tile of one round stores four pixels at a time.
+            const bool one_round = nrec <= (uint32_t)WTAB_RCAP;
+            for (uint32_t base = 0u; base < max(nrec, 1u); base += (uint32_t)WTAB_RCAP) {
+                if (base) __syncthreads();       // the round before has read its records
+                // 2: one lane per bin entry (that owns a pixel): its record
                 for (uint32_t i = (uint32_t)tid; i < m; i += RASTER_THREADS) {
                     const bool mine = direct || ((L.winners[i >> 5].x >> (i & 31u)) & 1u);
                     const uint32_t rid = mine ? rid_of(i) - base : 0xFFFFFFFFu;
                     if (rid >= (uint32_t)WTAB_RCAP) continue;
-                    if constexpr (FIRST) {           // (one call of build: the gathered record of the first pass, or this pass's, in the same registers)
-                        if (i >= (uint32_t)RASTER_THREADS) {
-                            slot_first = a.bins[b0 + i] & bin_mask;
-                            G_first = gather(slot_first);
-                        }
-                        build(rid, slot_first, G_first);
-                    } else {
-                        const uint32_t slot = a.bins[b0 + i] & bin_mask;
-                        build(rid, slot, gather(slot));
+                    if (i >= (uint32_t)RASTER_THREADS || base) {      // (else: gathered before pass 1)
+                        slot_first = a.bins[b0 + i] & bin_mask;
+                        G_first = gather(slot_first);
                     }
+                    build(rid, slot_first, G_first);
                 }
-            };
-            if (nrec <= (uint32_t)WTAB_RCAP) {
-                build_round(0u, std::true_type{});
                 __syncthreads();
                 // 3: every pixel from its winner's record
 #pragma unroll 1
@@ -2183,14 +2178,18 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                     const uint32_t ps[4] = {pp.x & 0xFFFFu, pp.x >> 16, pp.y & 0xFFFFu, pp.y >> 16};
                     uint32_t cpix[4];
                     float dpix[4];
+                    uint32_t stored = 0u;              // (rounds) which of the four pixels this round stores
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         cpix[k] = 0u;                  // Pixel(0,0,0,0) (:205)
                         dpix[k] = INFINITY;            // (:206)
-                        if (ps[k] != 0xFFFFu && x + k <= X1) shade(rid_of(ps[k]), x + k, y, cpix[k], dpix[k]);
+                        if (x + k > X1) continue;
+                        if (ps[k] == 0xFFFFu) { if (base == 0u) stored |= 1u << k; continue; }
+                        const uint32_t rid = rid_of(ps[k]) - base;
+                        if (rid < (uint32_t)WTAB_RCAP) { shade(rid, x + k, y, cpix[k], dpix[k]); stored |= 1u << k; }
                     }
                     const size_t at = (size_t)(y - a.tg.row_begin) * (size_t)W + (size_t)x;   // App.swift:351-360
-                    if (vec_ok && x + 3 <= X1) {
+                    if (one_round && vec_ok && x + 3 <= X1) {
                         typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
                         typedef float f32x4 __attribute__((ext_vector_type(4)));
                         u32x4 cv = {cpix[0], cpix[1], cpix[2], cpix[3]};
@@ -2198,36 +2197,14 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                         f32x4 dv = {dpix[0], dpix[1], dpix[2], dpix[3]};
                         __builtin_nontemporal_store(dv, reinterpret_cast<f32x4*>(a.depth + at));
                     } else {
-                        for (int k = 0; k < 4 && x + k <= X1; k++) {
+                        // (several rounds, or the ragged right edge: pixel by pixel — a round stores the pixels whose winner it holds, the first
+                        // one also those without a winner)
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            if (!((stored >> k) & 1u)) continue;
                             reinterpret_cast<uint32_t*>(a.color)[at + k] = cpix[k];
                             a.depth[at + k] = dpix[k];
                         }
-                    }
-                }
-                return false;
-            }
-            // More winners than records fit (a tile of ~1 000 two-pixel triangles has ~600): rounds of WTAB_RCAP winners, every pixel
-            // stored by the round its winner falls into (and the pixels without one by the first) — one pixel at a time, small code.
-            for (uint32_t base = 0u; base < nrec; base += (uint32_t)WTAB_RCAP) {
-                if (base) __syncthreads();       // the round before has read its records
-                build_round(base, std::false_type{});
-                __syncthreads();
-#pragma unroll 1
-                for (int p = tid; p < TILE_W * TILE_H; p += RASTER_THREADS) {     // (consecutive lanes = consecutive pixels: coalesced 4-B stores)
-                    const int y = Y0 + p / TILE_W, x = X0 + p % TILE_W;
-                    if (y < Yp0 || y > Yp1 || x > X1) continue;
-                    const uint32_t q = pix[p];
-                    uint32_t c = 0u;                   // Pixel(0,0,0,0) (:205)
-                    float d = INFINITY;                // (:206)
-                    bool store = q == 0xFFFFu && base == 0u;
-                    if (q != 0xFFFFu) {
-                        const uint32_t rid = rid_of(q) - base;
-                        if (rid < (uint32_t)WTAB_RCAP) { shade(rid, x, y, c, d); store = true; }
-                    }
-                    if (store) {
-                        const size_t at = (size_t)(y - a.tg.row_begin) * (size_t)W + (size_t)x;
-                        reinterpret_cast<uint32_t*>(a.color)[at] = c;
-                        a.depth[at] = d;
                     }
                 }
             }

@@ -2003,8 +2003,9 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
     //      constants, the three depths, the vertex colours (normals, texture coordinates) — where the keys were;
     //   3  every pixel shades from its winner's record.
     // No original-index -> slot gather, two gather round trips per tile (the first one in flight across step 1) instead of up to
-    // nine, the setup runs ~6 times per tile instead of 32: cfg4 colour + depth 0.114 -> 0.103 ms (k_raster 57.6 -> 50.4 M vector
-    // instructions), cfg5 0.169 -> 0.152.  A tile with more winners than records fit (WTAB_RCAP) takes the per-thread path below.
+    // nine, the setup runs ~6 times per tile instead of 32: cfg4 colour + depth 0.114 -> 0.101 ms (k_raster 57.6 -> 50.4 M vector
+    // instructions), cfg5 0.168 -> 0.143, cfg5 textured 0.343 -> 0.284 (profiles/r04/winner_table_ab.txt).  A tile with more winners
+    // than records fit (WTAB_RCAP) goes through steps 2 and 3 in rounds.
     if constexpr (WTAB_OK) {
         // record: [0..9] weights (CPU rules: T() 4, cf 2, z 3, - ; Metal rules: p3 2, A0 B0 A1 B1, divider, z 3), [10..18] colours a b c,
         // extended stage: [19..27] normals a b c, [28..33] (u, v) a b c.  An odd stride in words: neighbouring records in different banks.
@@ -2215,14 +2216,14 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
     // 4 MB table; the keys hold the original index because it decides depth ties) — 8 independent loads in flight
     // instead of 4 + 4 behind each other — written back into the low words of the keys, which have done their job.
     static_assert(TILE_W * TILE_H / 4 == 2 * RASTER_THREADS, "two 4-pixel groups per thread");
-    const int pshift = wtab ? WTAB_LOCAL_BITS : 0;      // (a tile whose winners did not fit the table: the original index sits above the bin position)
+    // (reached by colour frames only when the keys carry no bin position: a bin of more than 4 096 entries, or the PLAIN kernels)
     if (want_color && a.reordered && VAR != 8 && VAR != 10 && VAR != 11) {
         uint32_t sl[8];
 #pragma unroll
         for (int g = 0; g < 8; g++) {
             const int p = (tid + (g >> 2) * RASTER_THREADS) * 4 + (g & 3);
             const unsigned long long key = keys[p];
-            const uint32_t prim = (ZTEST ? (uint32_t)key : 0xFFFFFFFFu - (uint32_t)key) >> pshift;
+            const uint32_t prim = ZTEST ? (uint32_t)key : 0xFFFFFFFFu - (uint32_t)key;
             sl[g] = (uint32_t)(key >> 32) < KEY_LIVE_BELOW ? a.inv[prim] : 0u;
         }
 #pragma unroll
@@ -2304,7 +2305,7 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
                 const unsigned long long key = keys[ly[g] * TILE_W + lx[g] + k];
                 const uint32_t hi = (uint32_t)(key >> 32);
                 const bool live = on[g] && hi < KEY_LIVE_BELOW && x[g] + k <= X1;
-                prim[g] = (ZTEST ? (uint32_t)key : 0xFFFFFFFFu - (uint32_t)key) >> pshift;
+                prim[g] = ZTEST ? (uint32_t)key : 0xFFFFFFFFu - (uint32_t)key;
                 d[g] = INFINITY;           // (:206)
                 need_rec[g] = live && want_color;
                 if (ZTEST && live) {

@@ -418,6 +418,9 @@ __device__ __forceinline__ PixBox unpack_box(uint2 r) {
 }
 __device__ __forceinline__ uint32_t size_class(const PixBox& b, int tx, int ty) {
     const int rows = min(b.y1, ty * TILE_H + TILE_H - 1) - max(b.y0, ty * TILE_H) + 1;
+    // (a box clipped to a tile never exceeds the default BIG_AREA: the column extent, the product and the compare are seven vector
+    // instructions per (triangle, tile) pair of k_bin's second walk for a class nobody gets)
+    if constexpr (BIG_AREA >= TILE_W * TILE_H) return (uint32_t)(rows - 1);
     const int cols = min(b.x1, tx * TILE_W + TILE_W - 1) - max(b.x0, tx * TILE_W) + 1;
     return rows * cols > BIG_AREA ? CLASS_BIG : (uint32_t)(rows - 1);
 }
@@ -1571,7 +1574,7 @@ __device__ __forceinline__ bool raster_tile(const RasterArgs& a, typename std::c
             bxb = min(maxx, X1);
             // the dense path below needs the exact small-coordinate arithmetic; everything else
             // (huge extents, large clipped area) is walked cooperatively in phase 2
-            big = !t.ch.small || maxx - minx >= 16384 || (yb - ya + 1) * (bxb - bxa + 1) > BIG_AREA;
+            big = !t.ch.small || maxx - minx >= 16384 || (BIG_AREA < TILE_W * TILE_H && (yb - ya + 1) * (bxb - bxa + 1) > BIG_AREA);
             // "large" = half of what this WAVE walks of the tile (all of its rows, or its share of them when the waves split
             // the rows): its spans are then about 32 pixels or more, the length the wide visits below are made for.  (Measured
             // against half the TILE, a wave that walks 8 rows never saw a large triangle and sent 64-pixel spans through the

@@ -203,6 +203,10 @@ def band_rows(height: int, parts: int, part: int):
     return a.value, b.value
 
 
+# status codes of include/swr.h that the binding itself looks at
+ERR_BAD_ARG, ERR_NO_SCENE = -1, -6
+
+
 class HostImage:
     """A page-locked host image from swr_host_alloc (what a .storageModeShared MTLBuffer is to the reference,
     App.swift:59-60), viewed as a NumPy array; every GPU copies its band straight into it (swr_present)."""
@@ -361,7 +365,7 @@ class Context:
                 x._busy.add(id(self))
         rc = self._L.swr_present(self._h, ptr(color), ptr(depth))
         if rc:
-            if rc in (-1, -6):          # SWR_ERR_BAD_ARG / SWR_ERR_NO_SCENE: refused before anything was enqueued
+            if rc in (ERR_BAD_ARG, ERR_NO_SCENE):          # refused before anything was enqueued
                 for x in added:
                     del self._present_refs[id(x)]
                     if isinstance(x, HostImage):

@@ -321,7 +321,7 @@ def test_gpu_winner_table_modes(gpu_ctx, oracle, swr, ntri, w, h, r, what, flags
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("flags,shader", [(DT, 2), (METAL, 1), (0, 2)])
-@pytest.mark.parametrize("ntri,w,h,r,what", WINNER_TABLE_SCENES[:5])
+@pytest.mark.parametrize("ntri,w,h,r,what", WINNER_TABLE_SCENES)
 def test_gpu_winner_table_modes_extended_stage(gpu_ctx, oracle, swr, ntri, w, h, r, what, flags, shader):
     s = swr.scenes.random_soup(ntri, w, h, 777 + ntri % 89, r_ndc=r, flags=flags, margin=1.05)
     sh = swr.scenes.random_shading(s.vertices.shape[0], 31 + shader, shader, shininess_log2=3)
